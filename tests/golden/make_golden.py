@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference's own
+``models/*`` (read-only tree at /root/reference) on CPU/fp32 in the build container.
+
+Only inputs and expected outputs are written (``*.npz``); no reference source travels.
+Weights are never stored: both sides fill parameters with the closed-form initialiser
+``oracle.hri_emo_oracle.closed_form_init_`` (same ``named_parameters()`` order/keys).
+
+Run (build container only -- /root/reference does not exist on the GPU box):
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+from oracle.hri_emo_oracle import closed_form_init_, train_step_loss  # noqa: E402
+from models.fusion_with_emotion_decoder import FusionWithEmotionDecoder  # noqa: E402  (reference)
+from models.cross_modal_block_tacfn import CrossModalBlock  # noqa: E402  (reference)
+from models.beta_gate_tacfn import BetaGate  # noqa: E402  (reference)
+from models.emotion_decoder import EmotionDecoder  # noqa: E402  (reference)
+
+torch.set_num_threads(4)
+
+
+def inputs(seed, B, Ta, Tt, d, ragged):
+    g = torch.Generator().manual_seed(seed)
+    h_a = torch.randn(B, Ta, d, generator=g)
+    h_t = torch.randn(B, Tt, d, generator=g)
+    if not ragged:
+        return h_a, h_t, None, None
+    la = torch.randint(max(1, Ta // 2), Ta + 1, (B,), generator=g)
+    lt = torch.randint(max(1, Tt // 2), Tt + 1, (B,), generator=g)
+    la[0], lt[0] = Ta, Tt                      # one full-length sample
+    m_a = torch.arange(Ta)[None, :] >= la[:, None]
+    m_t = torch.arange(Tt)[None, :] >= lt[:, None]
+    return h_a, h_t, m_a, m_t
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if v is None:
+            continue
+        out[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, keys={len(out)}")
+
+
+def grad_record(model, prefix="g."):
+    """Full grads for 1-D params and emotion_queries; L2 norm + 64 strided samples otherwise."""
+    rec = {}
+    for name, p in model.named_parameters():
+        g = p.grad
+        rec[prefix + "norm." + name] = g.norm().reshape(1)
+        if g.dim() <= 1 or name.endswith("emotion_queries"):
+            rec[prefix + "full." + name] = g.clone()
+        else:
+            flat = g.reshape(-1)
+            idx = torch.linspace(0, flat.numel() - 1, 64).long()
+            rec[prefix + "samp." + name] = flat[idx].clone()
+    return rec
+
+
+def attn_record(pack):
+    rec = {}
+    for li, m in enumerate(pack["encoder"]):
+        for k, v in m.items():
+            rec[f"enc.{li}.{k}"] = v
+    for li, v in enumerate(pack["decoder"]):
+        rec[f"dec.{li}"] = v
+    return rec
+
+
+def fusion_cases():
+    cfg1 = dict(d_model=128, num_emotions=4, n_heads=8)
+    B, Ta, Tt, d = 8, 32, 16, 128
+
+    # (1) cfg 1 eval, no masks  (BASELINE.json configs[0])
+    m = closed_form_init_(FusionWithEmotionDecoder(**cfg1)).eval()
+    h_a, h_t, _, _ = inputs(11, B, Ta, Tt, d, False)
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t)
+    npz("cfg1_eval_nomask", h_a=h_a, h_t=h_t, logits=logits, beta=beta, z=z)
+
+    # (2)+(3) cfg 1 eval, ragged masks, attention maps
+    h_a, h_t, m_a, m_t = inputs(12, B, Ta, Tt, d, True)
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+        l2, b2, z2, pack = m(h_a, h_t, m_a, m_t, return_attention=True)
+    assert torch.allclose(logits, l2, atol=1e-5)
+    npz("cfg1_eval_ragged", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, logits=logits, beta=beta, z=z,
+        **attn_record(pack))
+
+    # (6) 2-D inputs -> _ensure_3d
+    g = torch.Generator().manual_seed(13)
+    xa, xt = torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+    with torch.no_grad():
+        logits, beta, z = m(xa, xt)
+    npz("cfg1_eval_2d_inputs", h_a=xa, h_t=xt, logits=logits, beta=beta, z=z)
+
+    # (7) one sample whose text keys are all PAD -> NaN for that sample only
+    h_a, h_t, m_a, m_t = inputs(14, B, Ta, Tt, d, True)
+    m_t[3, :] = True
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+    npz("cfg1_eval_allpad_row", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, logits=logits, beta=beta, z=z)
+
+    # (4) train mode, dropout=0, loss of the seq-level trainer, grads; then clip + AdamW step
+    mt = closed_form_init_(FusionWithEmotionDecoder(dropout=0.0, **cfg1)).train()
+    h_a, h_t, m_a, m_t = inputs(15, B, Ta, Tt, d, True)
+    h_a.requires_grad_(True)
+    h_t.requires_grad_(True)
+    y = (torch.rand(B, 4, generator=torch.Generator().manual_seed(16)) < 0.3).float()
+    logits, beta, z = mt(h_a, h_t, m_a, m_t)
+    loss = train_step_loss(logits, beta, y)
+    loss.backward()
+    rec = grad_record(mt)
+    before = {n: p.detach().clone() for n, p in mt.named_parameters()}
+    opt = torch.optim.AdamW(mt.parameters(), lr=1e-4, weight_decay=1e-2)
+    total_norm = torch.nn.utils.clip_grad_norm_(mt.parameters(), max_norm=5.0)
+    opt.step()
+    for n, p in mt.named_parameters():
+        rec["delta.norm." + n] = (p.detach() - before[n]).norm().reshape(1)
+    npz("cfg1_train_p0", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, y=y, logits=logits, beta=beta, z=z,
+        loss=loss.reshape(1), total_grad_norm=total_norm.reshape(1), g_h_a=h_a.grad, g_h_t=h_t.grad, **rec)  # rec holds clones taken BEFORE the clip
+
+    # (5) real head_dim: d=768, H=8 (hd=96), lengths not multiples of 16
+    cfg = dict(d_model=768, num_emotions=6, n_heads=8)
+    B2, Ta2, Tt2 = 2, 48, 20
+    m768 = closed_form_init_(FusionWithEmotionDecoder(dropout=0.0, **cfg)).eval()
+    h_a, h_t, m_a, m_t = inputs(17, B2, Ta2, Tt2, 768, True)
+    with torch.no_grad():
+        logits, beta, z, pack = m768(h_a, h_t, m_a, m_t, return_attention=True)
+    npz("hd96_eval_ragged", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, logits=logits, beta=beta, z=z,
+        **attn_record(pack))
+    m768.train()
+    y = (torch.rand(B2, 6, generator=torch.Generator().manual_seed(18)) < 0.3).float()
+    h_a.requires_grad_(True)
+    h_t.requires_grad_(True)
+    logits, beta, z = m768(h_a, h_t, m_a, m_t)
+    loss = train_step_loss(logits, beta, y)
+    loss.backward()
+    npz("hd96_train_p0", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, y=y, logits=logits, beta=beta, z=z,
+        loss=loss.reshape(1), g_h_a=h_a.grad, g_h_t=h_t.grad, **grad_record(m768))
+
+
+def component_cases():
+    d, H, B = 128, 8, 4
+    # CrossModalBlock alone (a1-a5)
+    blk = closed_form_init_(CrossModalBlock(d_model=d, n_heads=H, dropout=0.1)).eval()
+    h_a, h_t, m_a, m_t = inputs(21, B, 24, 10, d, True)
+    with torch.no_grad():
+        oa, ot, maps = blk(h_a, h_t, m_a, m_t, return_attention=True)
+    npz("block_eval_ragged", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, out_a=oa, out_t=ot,
+        **{"map." + k: v for k, v in maps.items()})
+
+    # BetaGate alone: L_a != L_t (truncate to L_t) and L_a == L_t (a7, a8)
+    gate = closed_form_init_(BetaGate(d_model=d, hidden_dim=32)).eval()
+    with torch.no_grad():
+        hf, beta = gate(h_a, h_t, m_a, m_t)
+    npz("gate_eval_ragged", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, h_fusion=hf, beta=beta)
+    h_a2, h_t2, _, _ = inputs(22, B, 12, 12, d, False)
+    with torch.no_grad():
+        hf, beta = gate(h_a2, h_t2)
+    npz("gate_eval_equal_len_nomask", h_a=h_a2, h_t=h_t2, h_fusion=hf, beta=beta)
+
+    # EmotionDecoder alone (a9, a10)
+    dec = closed_form_init_(EmotionDecoder(d_model=d, num_emotions=5, n_heads=H, num_layers=2,
+                                           dim_feedforward=64, dropout=0.1)).eval()
+    mem = h_t
+    with torch.no_grad():
+        z, logits, maps = dec(mem, m_t, return_attention=True)
+    npz("decoder_eval_ragged", memory=mem, mask=m_t, z=z, logits=logits,
+        **{f"map.{i}": v for i, v in enumerate(maps)})
+
+
+if __name__ == "__main__":
+    fusion_cases()
+    component_cases()
