@@ -1,0 +1,73 @@
+"""ctypes binding of libhriemo.so (include/hriemo.h).  There is NO fallback: if the library is missing
+or a kernel call fails this raises -- the product path never routes around the HIP kernels."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhriemo.so")
+
+_C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float,
+      "Q": ctypes.c_ulonglong, "I": ctypes.c_uint}
+
+# name -> (argument codes, result): p pointer, i int, l long, f float, Q u64, I u32
+_SIGS = {
+    "hriemo_gemm_bf16": ("iiiiiplplplipipliplp", "i"),
+    "hriemo_attn_fwd": ("plplplplppiiiiifQIip", "i"),
+    "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQIip", "i"),
+    "hriemo_attn_probs": ("plplpppiiiiifQIip", "i"),
+    "hriemo_add_ln_fwd": ("pppppppiiffQIlp", "i"),
+    "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),
+    "hriemo_add_ln_bwd": ("pppppppppppiifQIlpp", "i"),
+    "hriemo_colsum_workspace_bytes": ("ii", "l"),
+    "hriemo_colsum_bf16": ("pliipipp", "i"),
+    "hriemo_cast_f32_to_bf16": ("pplp", "i"),
+    "hriemo_cast_bf16_to_f32": ("pplp", "i"),
+    "hriemo_dropout_bf16": ("pplifQIlp", "i"),
+    "hriemo_expand_rows": ("ppilp", "i"),
+    "hriemo_rowdot_fwd": ("ppppiip", "i"),
+    "hriemo_rowdot_bwd": ("ppppppiip", "i"),
+    "hriemo_pool_chunks": ("i", "i"),
+    "hriemo_ln_pool_fwd": ("ppppppppiiiifp", "i"),
+    "hriemo_gate_input": ("ppppiiiipppp" + "p", "i"),
+    "hriemo_sigmoid_beta": ("pppiip", "i"),
+    "hriemo_fuse_fwd": ("ppppiiip", "i"),
+    "hriemo_fuse_bwd_dw": ("ppppiiip", "i"),
+    "hriemo_gate_dpre": ("pippp" + "iip", "i"),
+    "hriemo_gate_input_bwd": ("ppppppiip", "i"),
+    "hriemo_ln_pool_bwd_workspace_bytes": ("iii", "l"),
+    "hriemo_ln_pool_bwd": ("pipippppppppp" + "iiipp", "i"),
+    "hriemo_prof_enable": ("i", "i"),
+    "hriemo_prof_nclass": ("", "i"),
+    "hriemo_prof_collect": ("ippp", "i"),
+    "hriemo_abi_version": ("", "i"),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C hri-emo_amd/csrc` (or __graft_entry__.build()). "
+                "There is no CPU/eager fallback for this path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = [_C[c] for c in args]
+            fn.restype = _C[res]
+        L.hriemo_last_error.restype = ctypes.c_char_p
+        L.hriemo_last_error.argtypes = []
+        L.hriemo_prof_name.restype = ctypes.c_char_p
+        L.hriemo_prof_name.argtypes = [ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-status entry point; raise with the library's message on failure."""
+    L = lib()
+    rc = getattr(L, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.hriemo_last_error().decode()}")

@@ -1,0 +1,474 @@
+"""Host side of the kernels: thin tensor->pointer wrappers over the C ABI (include/hriemo.h) and the
+``torch.autograd.Function``s the mirrored nn.Modules (``models/``) are built from.
+
+One Function per residual sub-layer of the reference (each is "LayerNorm(x + dropout(sub(x)))"):
+  SelfAttnLN   models/cross_modal_block_tacfn.py:74-81,85-92 ; models/emotion_decoder.py:42-43
+  CrossAttnLN  models/cross_modal_block_tacfn.py:98-105,111-118 ; models/emotion_decoder.py:48-55
+  FFNLN        models/cross_modal_block_tacfn.py:106,119 ; models/emotion_decoder.py:58-59
+  BetaGateFn   models/beta_gate_tacfn.py:68-118
+  ExpandFn / RowDotFn  models/emotion_decoder.py:127,155
+torch is used for device memory, streams and autograd bookkeeping only; all arithmetic on the path is in
+libhriemo.so.  Activations are bf16, statistics/parameter gradients fp32.  No CPU fallback exists.
+"""
+import itertools
+import math
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "hri_emo_amd runs on MI355X only: got a CPU tensor. There is no CPU fallback for this path "
+            "(move the module and its inputs to 'cuda').")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, slot=0):
+    """Caller-owned scratch for the C ABI (split-K slabs, column-sum partials); grows monotonically."""
+    key = (device.index, slot)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        n = max(int(nbytes), 64 << 20) // 4 + 16
+        t = torch.empty(n, dtype=torch.float32, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+_site_counter = itertools.count(1)
+
+
+def new_site_base():
+    """Unique dropout-site id base for a module instance (3 sites per sub-layer)."""
+    return next(_site_counter) * 4
+
+
+def next_seed(training):
+    """Per-call dropout seed drawn from torch's CPU generator (reproducible under torch.manual_seed;
+    identical on every DP rank that seeded identically)."""
+    if not training:
+        return 0
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class Shadows:
+    """bf16 copies of fp32 master weights, refreshed when the master changes (optimizer step,
+    load_state_dict, .to())."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, p):
+        key = id(p)
+        ent = self._d.get(key)
+        ver = (p._version, p.data_ptr())
+        if ent is None or ent[0] != ver or ent[1].device != p.device:
+            s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
+                torch.empty(p.shape, dtype=BF16, device=p.device)
+            _require_gpu(p)
+            src = p.detach()
+            if src.dtype != torch.float32 or not src.is_contiguous():
+                src = src.float().contiguous()
+            _lib.call("hriemo_cast_f32_to_bf16", _p(src), _p(s), src.numel(), _stream())
+            ent = (ver, s)
+            self._d[key] = ent
+        return ent[1]
+
+
+def to_bf16(x):
+    return x if x.dtype == BF16 else x.to(BF16)
+
+
+def mask_u8(mask, B, L):
+    if mask is None:
+        return None
+    if mask.shape != (B, L):
+        raise ValueError(f"key_padding_mask shape {tuple(mask.shape)} != {(B, L)}")
+    m = mask.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+
+
+# ----------------------------------------------------------------------------- raw kernel wrappers
+def gemm(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, c_f32=False, bias=None, epi=0, aux=None, ldaux=0, accumulate=False):
+    ws = workspace(64 << 20, C.device) if c_f32 else None
+    _lib.call("hriemo_gemm_bf16", ta, tb, M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, int(c_f32), _p(bias), epi,
+              _p(aux), ldaux, int(accumulate), _p(ws), ws.numel() * 4 if ws is not None else 0, _stream())
+
+
+def linear_fwd(x, w16, bias, relu=False, out_f32=False):
+    """x [M,K] bf16 (row stride free), w16 [N,K] bf16 -> [M,N]"""
+    M, K = x.shape
+    N = w16.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=x.device)
+    gemm(0, 0, M, N, K, x, x.stride(0), w16, w16.stride(0), y, N, c_f32=out_f32, bias=bias, epi=1 if relu else 0)
+    return y
+
+
+def linear_dx(dy, w16, epi=0, aux=None):
+    """dX[M,K] = dY[M,N] . W[N,K]  (optionally * (aux>0) or + aux)"""
+    M, N = dy.shape
+    K = w16.shape[1]
+    dx = torch.empty((M, K), dtype=BF16, device=dy.device)
+    gemm(0, 1, M, K, N, dy, dy.stride(0), w16, w16.stride(0), dx, K, epi=epi, aux=aux,
+         ldaux=aux.stride(0) if aux is not None else 0)
+    return dx
+
+
+def linear_dw(dy, x, out):
+    """out[N,K] (fp32, row stride free) = dY[M,N]^T . X[M,K]"""
+    M, N = dy.shape
+    K = x.shape[1]
+    gemm(1, 1, N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True)
+
+
+def colsum(x, out):
+    M, N = x.shape
+    ws = workspace(_lib.lib().hriemo_colsum_workspace_bytes(M, N), x.device, slot=1)
+    _lib.call("hriemo_colsum_bf16", _p(x), x.stride(0), M, N, _p(out), 0, _p(ws), _stream())
+
+
+def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
+    o = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    _lib.call("hriemo_attn_fwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+              _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, site, b_off, _stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
+    delta = torch.empty_like(lse)
+    _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+              _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
+              _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, site, b_off, _stream())
+
+
+def attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off):
+    out = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device)
+    _lib.call("hriemo_attn_probs", _p(q), q.stride(0), _p(k), k.stride(0), _p(kpm), _p(lse), _p(out), B, H, Lq, Lk,
+              hd, float(p), seed, site, b_off, _stream())
+    return out
+
+
+def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off):
+    M, d = g.shape
+    y = torch.empty((M, d), dtype=BF16, device=g.device)
+    mean = torch.empty(M, dtype=torch.float32, device=g.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=g.device)
+    _lib.call("hriemo_add_ln_fwd", _p(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, _EPS, float(p),
+              seed, site, row_off, _stream())
+    return y, mean, rstd
+
+
+def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True):
+    M, d = g.shape
+    dev = g.device
+    dx = torch.empty((M, d), dtype=BF16, device=dev) if want_dx else None
+    dg = torch.empty((M, d), dtype=BF16, device=dev) if (p > 0 or not want_dx) else None
+    stats = torch.empty((3, d), dtype=torch.float32, device=dev)
+    ws = workspace(_lib.lib().hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
+    _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(stats[0]),
+              _p(stats[1]), _p(stats[2]), M, d, float(p), seed, site, row_off, _p(ws), _stream())
+    if dg is None:
+        dg = dx           # no dropout: both branches get the same gradient
+    return dx, dg, stats[0], stats[1], stats[2]
+
+
+def _heads(d, H):
+    if d % H != 0:
+        raise ValueError(f"d_model={d} not divisible by n_heads={H}")
+    hd = d // H
+    if hd not in (16, 32, 64, 96, 128):
+        raise ValueError(f"head_dim={hd} is not built (supported: 16, 32, 64, 96, 128)")
+    return hd
+
+
+def _contig_bf16(t):
+    t = to_bf16(t)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- sub-layer Functions
+class SelfAttnLN(torch.autograd.Function):
+    """y = LN(x + drop(out_proj(MHA_core(in_proj(x))))) ; returns (y, probs|None)"""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        _require_gpu(x)
+        B, L, d = x.shape
+        hd = _heads(d, H)
+        M = B * L
+        x2 = _contig_bf16(x).view(M, d)
+        w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
+        qkv = linear_fwd(x2, w_in16, b_in)
+        q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        o, lse = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off)
+        g = linear_fwd(o, w_out16, b_out)
+        y, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L)
+        probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
+        ctx.save_for_backward(x2, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
+        ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
+        ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
+        return y.view(B, L, d), probs
+
+    @staticmethod
+    def backward(ctx, dy, _dprobs):
+        x2, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
+        B, L, d, H, hd, p, seed, site, b_off = ctx.cfg
+        M = B * L
+        dev = x2.device
+        dy2 = _contig_bf16(dy).view(M, d)
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L)
+        dw_out = torch.empty((d, d), dtype=torch.float32, device=dev)
+        linear_dw(dg, o, dw_out)
+        do = linear_dx(dg, w_out16)
+        dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
+        attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                 lse, B, H, L, L, hd, kpm, p, seed, site, b_off)
+        dw_in = torch.empty((3 * d, d), dtype=torch.float32, device=dev)
+        linear_dw(dqkv, x2, dw_in)
+        db_in = torch.empty(3 * d, dtype=torch.float32, device=dev)
+        colsum(dqkv, db_in)
+        dx = linear_dx(dqkv, w_in16, epi=3, aux=ds)
+        return (dx.view(B, L, d), dw_in, db_in, dw_out, db_out, dgamma, dbeta) + (None,) * 8
+
+
+class CrossAttnLN(torch.autograd.Function):
+    """y = LN(xq + drop(out_proj(MHA_core(Wq xq, Wkv xkv)))) ; returns (y, probs|None)"""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        _require_gpu(xq)
+        B, Lq, d = xq.shape
+        Lk = xkv.shape[1]
+        hd = _heads(d, H)
+        xq2 = _contig_bf16(xq).view(B * Lq, d)
+        xkv2 = _contig_bf16(xkv).view(B * Lk, d)
+        w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
+        q = linear_fwd(xq2, w_in16[:d], b_in[:d])
+        kv = linear_fwd(xkv2, w_in16[d:], b_in[d:])
+        k, v = kv[:, :d], kv[:, d:]
+        o, lse = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off)
+        g = linear_fwd(o, w_out16, b_out)
+        y, mean, rstd = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq)
+        probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
+        ctx.save_for_backward(xq2, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
+        ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
+        ctx.mark_non_differentiable(*([probs] if probs is not None else []))
+        return y.view(B, Lq, d), probs
+
+    @staticmethod
+    def backward(ctx, dy, _dprobs):
+        xq2, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
+        B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
+        dev = xq2.device
+        dy2 = _contig_bf16(dy).view(B * Lq, d)
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * Lq)
+        dw_out = torch.empty((d, d), dtype=torch.float32, device=dev)
+        linear_dw(dg, o, dw_out)
+        do = linear_dx(dg, w_out16)
+        dq = torch.empty((B * Lq, d), dtype=BF16, device=dev)
+        dkv = torch.empty((B * Lk, 2 * d), dtype=BF16, device=dev)
+        attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm, p, seed,
+                 site, b_off)
+        dw_in = torch.empty((3 * d, d), dtype=torch.float32, device=dev)
+        linear_dw(dq, xq2, dw_in[:d])
+        linear_dw(dkv, xkv2, dw_in[d:])
+        db_in = torch.empty(3 * d, dtype=torch.float32, device=dev)
+        colsum(dq, db_in[:d])
+        colsum(dkv, db_in[d:])
+        dxq = linear_dx(dq, w_in16[:d], epi=3, aux=ds)
+        dxkv = linear_dx(dkv, w_in16[d:])
+        return (dxq.view(B, Lq, d), dxkv.view(B, Lk, d), dw_in, db_in, dw_out, db_out, dgamma, dbeta) + (None,) * 8
+
+
+class FFNLN(torch.autograd.Function):
+    """y = LN(x + drop(W2 . drop_mid(relu(W1 x + b1)) + b2))"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off):
+        _require_gpu(x)
+        B, L, d = x.shape
+        M = B * L
+        x2 = _contig_bf16(x).view(M, d)
+        w1_16, w2_16 = sh.get(w1), sh.get(w2)
+        h = linear_fwd(x2, w1_16, b1, relu=True)
+        hd_ = h
+        if p_mid > 0:
+            hd_ = torch.empty_like(h)
+            _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, site + 2, b_off * L,
+                      _stream())
+        g = linear_fwd(hd_, w2_16, b2)
+        y, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L)
+        ctx.save_for_backward(x2, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
+        ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)
+        return y.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h, hd_, g, mean, rstd, w1_16, w2_16, gamma = ctx.saved_tensors
+        B, L, d, p, p_mid, seed, site, b_off = ctx.cfg
+        M, F = h.shape
+        dev = x2.device
+        dy2 = _contig_bf16(dy).view(M, d)
+        ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L)
+        dw2 = torch.empty((d, F), dtype=torch.float32, device=dev)
+        linear_dw(dg, hd_, dw2)
+        da = linear_dx(dg, w2_16, epi=2, aux=h)          # * relu'(h)
+        if p_mid > 0:
+            _lib.call("hriemo_dropout_bf16", _p(da), _p(da), M, F, float(p_mid), seed, site + 2, b_off * L, _stream())
+        dw1 = torch.empty((F, d), dtype=torch.float32, device=dev)
+        linear_dw(da, x2, dw1)
+        db1 = torch.empty(F, dtype=torch.float32, device=dev)
+        colsum(da, db1)
+        dx = linear_dx(da, w1_16, epi=3, aux=ds)
+        return (dx.view(B, L, d), dw1, db1, dw2, db2, dgamma, dbeta) + (None,) * 6
+
+
+class BetaGateFn(torch.autograd.Function):
+    """(h_fusion, beta) = BetaGate(h_a, h_t, masks)  -- models/beta_gate_tacfn.py:68-118"""
+
+    @staticmethod
+    def forward(ctx, h_a, h_t, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t):
+        _require_gpu(h_a)
+        B, La, d = h_a.shape
+        Lt = h_t.shape[1]
+        L = La if La == Lt else Lt                      # :98-104 (align to the text length)
+        if La < L:
+            raise RuntimeError(f"BetaGate: audio length {La} < text length {Lt}; the reference cannot fuse this either")
+        dev = h_a.device
+        xa, xt = _contig_bf16(h_a), _contig_bf16(h_t)
+        f32 = dict(dtype=torch.float32, device=dev)
+        L_ = _lib.lib()
+        nca, nct = L_.hriemo_pool_chunks(La), L_.hriemo_pool_chunks(Lt)
+        An = torch.empty((B, L, d), dtype=BF16, device=dev)
+        Tn = torch.empty((B, L, d), dtype=BF16, device=dev)
+        mean_a, rstd_a = torch.empty(B * La, **f32), torch.empty(B * La, **f32)
+        mean_t, rstd_t = torch.empty(B * Lt, **f32), torch.empty(B * Lt, **f32)
+        pa, pt = torch.empty((B, nca, d), **f32), torch.empty((B, nct, d), **f32)
+        st = _stream()
+        _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa), B, La,
+                  L, d, _EPS, st)
+        _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt), B, Lt,
+                  L, d, _EPS, st)
+        gin = torch.empty((B, 4 * d), dtype=BF16, device=dev)
+        a_pool, t_pool = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
+        cnt = torch.empty((B, 2), **f32)
+        _lib.call("hriemo_gate_input", _p(pa), _p(pt), _p(kpm_a), _p(kpm_t), B, La, Lt, d, _p(gin), _p(a_pool),
+                  _p(t_pool), _p(cnt), st)
+        w1_16, w2_16 = sh.get(w1), sh.get(w2)
+        hid = linear_fwd(gin, w1_16, b1, relu=True)
+        pre = linear_fwd(hid, w2_16, b2, out_f32=True)
+        w = torch.empty((B, d), **f32)
+        beta = torch.empty((B, 1), **f32)
+        _lib.call("hriemo_sigmoid_beta", _p(pre), _p(w), _p(beta), B, d, st)
+        H = torch.empty((B, L, d), dtype=BF16, device=dev)
+        _lib.call("hriemo_fuse_fwd", _p(w), _p(An), _p(Tn), _p(H), B, L, d, st)
+        ctx.save_for_backward(xa, xt, An, Tn, mean_a, rstd_a, mean_t, rstd_t, gin, a_pool, t_pool, cnt, hid, w, w1_16,
+                              w2_16, ga, gt, kpm_a, kpm_t)
+        ctx.cfg = (B, La, Lt, L, d)
+        return H, beta
+
+    @staticmethod
+    def backward(ctx, dH, dbeta):
+        (xa, xt, An, Tn, mean_a, rstd_a, mean_t, rstd_t, gin, a_pool, t_pool, cnt, hid, w, w1_16, w2_16, ga, gt, kpm_a,
+         kpm_t) = ctx.saved_tensors
+        B, La, Lt, L, d = ctx.cfg
+        dev = xa.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _stream()
+        L_ = _lib.lib()
+        dH2 = _contig_bf16(dH) if dH is not None else torch.zeros((B, L, d), dtype=BF16, device=dev)
+        dbeta2 = dbeta.contiguous().float() if dbeta is not None else None
+        part = torch.empty((B, L_.hriemo_pool_chunks(L), d), **f32)
+        _lib.call("hriemo_fuse_bwd_dw", _p(dH2), _p(An), _p(Tn), _p(part), B, L, d, st)
+        dpre = torch.empty((B, d), dtype=BF16, device=dev)
+        _lib.call("hriemo_gate_dpre", _p(part), L, _p(dbeta2), _p(w), _p(dpre), B, d, st)
+        Hd = hid.shape[1]
+        dw2 = torch.empty((d, Hd), **f32)
+        linear_dw(dpre, hid, dw2)
+        db2 = torch.empty(d, **f32)
+        colsum(dpre, db2)
+        dhid = linear_dx(dpre, w2_16, epi=2, aux=hid)
+        dw1 = torch.empty((Hd, 4 * d), **f32)
+        linear_dw(dhid, gin, dw1)
+        db1 = torch.empty(Hd, **f32)
+        colsum(dhid, db1)
+        dgin = linear_dx(dhid, w1_16)
+        da, dt = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
+        _lib.call("hriemo_gate_input_bwd", _p(dgin), _p(a_pool), _p(t_pool), _p(cnt), _p(da), _p(dt), B, d, st)
+        dxa = torch.empty((B, La, d), dtype=BF16, device=dev)
+        dxt = torch.empty((B, Lt, d), dtype=BF16, device=dev)
+        sa, st_ = torch.empty((2, d), **f32), torch.empty((2, d), **f32)
+        ws = workspace(max(L_.hriemo_ln_pool_bwd_workspace_bytes(B, La, d),
+                           L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d)), dev, slot=1)
+        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(ga), _p(mean_a), _p(rstd_a),
+                  _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
+        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(gt), _p(mean_t), _p(rstd_t),
+                  _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
+        return dxa, dxt, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
+
+
+class ExpandFn(torch.autograd.Function):
+    """queries[N_e,d] -> [B,N_e,d] bf16   (models/emotion_decoder.py:127)"""
+
+    @staticmethod
+    def forward(ctx, q, B):
+        _require_gpu(q)
+        Ne, d = q.shape
+        out = torch.empty((B, Ne, d), dtype=BF16, device=q.device)
+        src = q.detach().float().contiguous()
+        _lib.call("hriemo_expand_rows", _p(src), _p(out), B, Ne * d, _stream())
+        ctx.cfg = (B, Ne, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Ne, d = ctx.cfg
+        g = _contig_bf16(dout).view(B, Ne * d)
+        dq = torch.empty(Ne * d, dtype=torch.float32, device=g.device)
+        colsum(g, dq)
+        return dq.view(Ne, d), None
+
+
+class RowDotFn(torch.autograd.Function):
+    """logits[M] = z[M,d] . w[1,d] + b   (models/emotion_decoder.py:155)"""
+
+    @staticmethod
+    def forward(ctx, z, w, b):
+        _require_gpu(z)
+        B, Ne, d = z.shape
+        z2 = _contig_bf16(z).view(B * Ne, d)
+        wf = w.detach().float().contiguous()
+        bf = b.detach().float().contiguous()
+        out = torch.empty(B * Ne, dtype=torch.float32, device=z.device)
+        _lib.call("hriemo_rowdot_fwd", _p(z2), _p(wf), _p(bf), _p(out), B * Ne, d, _stream())
+        ctx.save_for_backward(z2, wf)
+        ctx.cfg = (B, Ne, d)
+        return out.view(B, Ne)
+
+    @staticmethod
+    def backward(ctx, dl):
+        z2, wf = ctx.saved_tensors
+        B, Ne, d = ctx.cfg
+        dl2 = dl.contiguous().float().view(-1)
+        dz = torch.empty((B * Ne, d), dtype=BF16, device=z2.device)
+        dw = torch.empty((1, d), dtype=torch.float32, device=z2.device)
+        db = torch.empty(1, dtype=torch.float32, device=z2.device)
+        _lib.call("hriemo_rowdot_bwd", _p(dl2), _p(z2), _p(wf), _p(dz), _p(dw), _p(db), B * Ne, d, _stream())
+        return dz.view(B, Ne, d), dw, db

@@ -1,0 +1,665 @@
+// Flash-style multi-head attention core for gfx950 (the part nn.MultiheadAttention hides between
+// the in- and out-projection; reference call sites models/cross_modal_block_tacfn.py:74-117 and
+// models/emotion_decoder.py:42-54).  Q/K/V are read in place from the projection outputs
+// ([rows, ld] with the head at column h*HD), O is written head-concatenated for the out-projection.
+//
+// Layout choices (MFMA 16x16x32 bf16, wave64):
+//  * forward / dQ: scores are produced TRANSPOSED, S^T = K.Q^T, so one lane owns one query row
+//    (col = lane&15) and 4 keys per 16-key subtile; the row max/sum needs two xor-shuffles only,
+//    and P (resp. dS) feeds the next MFMA straight from registers as the B operand with the
+//    permuted k-order key = 16*(j>>2) + 4*(lane>>4) + (j&3); the other operand (V^T resp. K^T)
+//    is fetched in that same order with ds_read_b64_tr_b16 from the row-major LDS tile.
+//  * dK/dV: scores are produced un-transposed (key on the lane), so P / dS are again B operands
+//    for the reductions over the query index; dK and dV of a key block live in registers while the
+//    block sweeps all queries: no atomics, deterministic.
+//  * LDS tiles are [rows][HD] bf16 with row stride HDP*2+32 bytes: conflict-free for both the
+//    ds_read_b128 row reads and the transposed reads (8 consecutive rows -> 8 distinct 32-B windows).
+//  * key-padding mask = additive -inf; a row whose keys are all PAD yields NaN like the reference.
+//  * attention dropout is replayed from a counter hash (common.h), nothing is stored.
+#include "common.h"
+
+struct AttnArgs {
+  const bf16_t *Q, *K, *V;
+  long ldq, ldk, ldv;
+  bf16_t* O; long ldo;
+  const bf16_t* dO; long lddo;
+  bf16_t *dQ, *dK, *dV;
+  long lddq, lddk, lddv;
+  const uint8_t* kpm;
+  float* lse;
+  float* delta;
+  float* probs;        // [B, Lq, Lk] head-averaged probabilities (export kernel only)
+  int B, H, Lq, Lk;
+  float scale;
+  uint32_t thr16; float inv_keep; uint64_t seed; uint32_t site; int b_offset;
+};
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+template <int HD> struct AttnGeom {
+  static constexpr int HDP = (HD + 31) / 32 * 32;
+  static constexpr int KS = HDP / 32;     // k-steps over the head dim
+  static constexpr int DT = HD / 16;      // 16-wide output tiles over the head dim
+  static constexpr int STRIDE = HDP * 2 + 32;
+  static constexpr int CH = HD / 8;       // 16-byte chunks per row (data)
+  static constexpr int CHP = HDP / 8;     // 16-byte chunks per row (incl. zero pad)
+};
+
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.f;
+  return z;
+}
+
+// transposed fragment: lane (g,i) gets T[rows row0+4g+{0..3} and row0+16+4g+{0..3}][col0+i]
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int stride, int row0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const char* a0 = tile + (row0 + 4 * g + (i >> 2)) * stride + (col0 + 4 * (i & 3)) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))a0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(a0 + 16 * stride));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int stride, int row, int chunk) {
+  return *(LDS_PTR(const bf16x8))(tile + row * stride + chunk * 16);
+}
+
+// cooperative load of a [NR rows][HD] tile (rows >= nvalid and pad columns zero-filled)
+template <int HD, int NR, int NT>
+__device__ __forceinline__ void load_tile(char* tile, const bf16_t* base, long ld, int row_first, int nrows_total, int tid) {
+  using G = AttnGeom<HD>;
+  for (int id = tid; id < NR * G::CHP; id += NT) {
+    const int r = id / G::CHP, c = id - r * G::CHP;
+    bf16x8 v = zero8();
+    if (row_first + r < nrows_total && c < G::CH) v = *(const bf16x8*)(base + (long)(row_first + r) * ld + c * 8);
+    *(LDS_PTR(bf16x8))(tile + r * G::STRIDE + c * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <int HD, int NW, int QW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
+  using G = AttnGeom<HD>;
+  constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * STRIDE + 64 * 4];
+  char* Kt = lds;
+  char* Vt = lds + 64 * STRIDE;
+  float* mb = (float*)(lds + 2 * 64 * STRIDE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int qbase = blockIdx.x * (NW * QW * 16) + wave * QW * 16;
+
+  bf16x8 qf[QW][KS];
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs) {
+    const int qc = min(qbase + qs * 16 + i, a.Lq - 1);
+    const bf16_t* qp = a.Q + ((long)b * a.Lq + qc) * a.ldq + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      qf[qs][ks] = (e < HD) ? *(const bf16x8*)(qp + e) : zero8();
+    }
+  }
+  f32x4 o[QW][DT];
+  float m[QW], l[QW];
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs) {
+    m[qs] = -INFINITY; l[qs] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float sl2 = a.scale * LOG2E;
+  const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  const bf16_t* Kb = a.K + (long)b * a.Lk * a.ldk + h * HD;
+  const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
+  const int nkt = (a.Lk + 63) >> 6;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    load_tile<HD, 64, NT>(Kt, Kb, a.ldk, kt * 64, a.Lk, tid);
+    load_tile<HD, 64, NT>(Vt, Vb, a.ldv, kt * 64, a.Lk, tid);
+    if (tid < 64) {
+      const int key = kt * 64 + tid;
+      const bool pad = key >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
+      mb[tid] = pad ? -INFINITY : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 s[QW][4];
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) s[qs][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = row_frag(Kt, STRIDE, n * 16 + i, ks * 4 + g);
+#pragma unroll
+        for (int qs = 0; qs < QW; ++qs) s[qs][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][ks], s[qs][n], 0, 0, 0);
+      }
+
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[qs][n][r] = s[qs][n][r] * sl2 + bias[r];
+          mx = fmaxf(mx, s[qs][n][r]);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(m[qs], mx);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = exp2f(m[qs] - msafe);
+      m[qs] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[qs][n][r] - msafe);
+          s[qs][n][r] = p;
+          rs += p;
+        }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      l[qs] = l[qs] * alpha + rs;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[qs][dt] *= alpha;
+      if (a.thr16 != 0) {
+        const uint32_t q = (uint32_t)(qbase + qs * 16 + i);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t key = (uint32_t)(kt * 64 + n * 16 + 4 * g + r);
+            s[qs][n][r] = keep16(key32, q, key, a.thr16) ? s[qs][n][r] * a.inv_keep : 0.f;
+          }
+      }
+    }
+
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pf[QW];
+#pragma unroll
+      for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[qs][j] = (bf16_t)s[qs][2 * s2 + (j >> 2)][j & 3];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8 vf = tr_frag(Vt, STRIDE, 32 * s2, dt * 16, lane);
+#pragma unroll
+        for (int qs = 0; qs < QW; ++qs) o[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qs], o[qs][dt], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs) {
+    const int q = qbase + qs * 16 + i;
+    if (q >= a.Lq) continue;
+    const float inv = 1.f / l[qs];   // l == 0 (all keys PAD) -> 0 * inf = NaN, as the reference
+    bf16_t* op = a.O + ((long)b * a.Lq + q) * a.ldo + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(o[qs][dt][r] * inv);
+      *(bf16x4*)(op + dt * 16) = w;
+    }
+    if (g == 0 && a.lse != nullptr) a.lse[((long)b * a.H + h) * a.Lq + q] = (m[qs] + log2f(l[qs])) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dQ (+ delta)
+template <int HD, int NW, int QW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) {
+  using G = AttnGeom<HD>;
+  constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * STRIDE + 64 * 4];
+  char* Kt = lds;
+  char* Vt = lds + 64 * STRIDE;
+  float* mb = (float*)(lds + 2 * 64 * STRIDE);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int qbase = blockIdx.x * (NW * QW * 16) + wave * QW * 16;
+
+  bf16x8 qf[QW][KS], dof[QW][KS];
+  float lse2[QW], dl[QW];
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs) {
+    const int q = qbase + qs * 16 + i;
+    const int qc = min(q, a.Lq - 1);
+    const bf16_t* qp = a.Q + ((long)b * a.Lq + qc) * a.ldq + h * HD;
+    const bf16_t* dop = a.dO + ((long)b * a.Lq + qc) * a.lddo + h * HD;
+    const bf16_t* op = a.O + ((long)b * a.Lq + qc) * a.ldo + h * HD;
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      if (e < HD) {
+        qf[qs][ks] = *(const bf16x8*)(qp + e);
+        dof[qs][ks] = *(const bf16x8*)(dop + e);
+        const bf16x8 ov = *(const bf16x8*)(op + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)dof[qs][ks][j] * (float)ov[j];
+      } else {
+        qf[qs][ks] = zero8();
+        dof[qs][ks] = zero8();
+      }
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    dl[qs] = part;
+    const long li = ((long)b * a.H + h) * a.Lq + qc;
+    lse2[qs] = a.lse[li] * LOG2E;
+    if (g == 0 && q < a.Lq) a.delta[li] = part;
+  }
+  f32x4 dq[QW][DT];
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dq[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float sl2 = a.scale * LOG2E;
+  const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  const bf16_t* Kb = a.K + (long)b * a.Lk * a.ldk + h * HD;
+  const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
+  const int nkt = (a.Lk + 63) >> 6;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    load_tile<HD, 64, NT>(Kt, Kb, a.ldk, kt * 64, a.Lk, tid);
+    load_tile<HD, 64, NT>(Vt, Vb, a.ldv, kt * 64, a.Lk, tid);
+    if (tid < 64) {
+      const int key = kt * 64 + tid;
+      const bool pad = key >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
+      mb[tid] = pad ? -INFINITY : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 s[QW][4], dp[QW][4];
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        s[qs][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[qs][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = row_frag(Kt, STRIDE, n * 16 + i, ks * 4 + g);
+        const bf16x8 vf = row_frag(Vt, STRIDE, n * 16 + i, ks * 4 + g);
+#pragma unroll
+        for (int qs = 0; qs < QW; ++qs) {
+          s[qs][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][ks], s[qs][n], 0, 0, 0);
+          dp[qs][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qs][ks], dp[qs][n], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int qs = 0; qs < QW; ++qs) {
+      const uint32_t q = (uint32_t)(qbase + qs * 16 + i);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[qs][n][r] * sl2 + bias[r] - lse2[qs]);
+          float dpd = dp[qs][n][r];
+          if (a.thr16 != 0) {
+            const uint32_t key = (uint32_t)(kt * 64 + n * 16 + 4 * g + r);
+            dpd = keep16(key32, q, key, a.thr16) ? dpd * a.inv_keep : 0.f;
+          }
+          s[qs][n][r] = p * (dpd - dl[qs]);
+        }
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 dsf[QW];
+#pragma unroll
+      for (int qs = 0; qs < QW; ++qs)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsf[qs][j] = (bf16_t)s[qs][2 * s2 + (j >> 2)][j & 3];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8 ktf = tr_frag(Kt, STRIDE, 32 * s2, dt * 16, lane);
+#pragma unroll
+        for (int qs = 0; qs < QW; ++qs) dq[qs][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[qs], dq[qs][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs) {
+    const int q = qbase + qs * 16 + i;
+    if (q >= a.Lq) continue;
+    bf16_t* dqp = a.dQ + ((long)b * a.Lq + q) * a.lddq + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(dq[qs][dt][r] * a.scale);
+      *(bf16x4*)(dqp + dt * 16) = w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+template <int HD, int NW, int KW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  using G = AttnGeom<HD>;
+  constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char lds[2 * 32 * STRIDE + 2 * 32 * 4];
+  char* Qt = lds;
+  char* dOt = lds + 32 * STRIDE;
+  float* lse_s = (float*)(lds + 2 * 32 * STRIDE);
+  float* del_s = lse_s + 32;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int kbase = blockIdx.x * (NW * KW * 16) + wave * KW * 16;
+
+  bf16x8 kreg[KW][KS], vreg[KW][KS];
+  bool kvalid[KW];
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) {
+    const int key = kbase + kw * 16 + i;
+    const int kc = min(key, a.Lk - 1);
+    kvalid[kw] = key < a.Lk && !(a.kpm != nullptr && a.kpm[(long)b * a.Lk + kc] != 0);
+    const bf16_t* kp = a.K + ((long)b * a.Lk + kc) * a.ldk + h * HD;
+    const bf16_t* vp = a.V + ((long)b * a.Lk + kc) * a.ldv + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      kreg[kw][ks] = (e < HD) ? *(const bf16x8*)(kp + e) : zero8();
+      vreg[kw][ks] = (e < HD) ? *(const bf16x8*)(vp + e) : zero8();
+    }
+  }
+  f32x4 dk[KW][DT], dv[KW][DT];
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      dk[kw][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[kw][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  const float sl2 = a.scale * LOG2E;
+  const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
+  const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
+  const long lbase = ((long)b * a.H + h) * a.Lq;
+  const int nqt = (a.Lq + 31) >> 5;
+
+  for (int qt = 0; qt < nqt; ++qt) {
+    __syncthreads();
+    load_tile<HD, 32, NT>(Qt, Qb, a.ldq, qt * 32, a.Lq, tid);
+    load_tile<HD, 32, NT>(dOt, dOb, a.lddo, qt * 32, a.Lq, tid);
+    if (tid < 32) {
+      const int q = qt * 32 + tid;
+      lse_s[tid] = q < a.Lq ? a.lse[lbase + q] * LOG2E : INFINITY;   // +inf -> p = 0 for rows past Lq
+      del_s[tid] = q < a.Lq ? a.delta[lbase + q] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 s[KW][2], dp[KW][2];
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        s[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 qfr = row_frag(Qt, STRIDE, qs * 16 + i, ks * 4 + g);
+        const bf16x8 dofr = row_frag(dOt, STRIDE, qs * 16 + i, ks * 4 + g);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          s[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kreg[kw][ks], s[kw][qs], 0, 0, 0);
+          dp[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vreg[kw][ks], dp[kw][qs], 0, 0, 0);
+        }
+      }
+    bf16x8 pf[KW], dsf[KW];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const f32x4 lse4 = *(LDS_PTR(const f32x4))(lse_s + qs * 16 + 4 * g);
+      const f32x4 del4 = *(LDS_PTR(const f32x4))(del_s + qs * 16 + 4 * g);
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const uint32_t key = (uint32_t)(kbase + kw * 16 + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = kvalid[kw] ? exp2f(s[kw][qs][r] * sl2 - lse4[r]) : 0.f;
+          float pd = p, dpd = dp[kw][qs][r];
+          if (a.thr16 != 0) {
+            const uint32_t q = (uint32_t)(qt * 32 + qs * 16 + 4 * g + r);
+            const bool keep = keep16(key32, q, key, a.thr16);
+            pd = keep ? p * a.inv_keep : 0.f;
+            dpd = keep ? dpd * a.inv_keep : 0.f;
+          }
+          pf[kw][qs * 4 + r] = (bf16_t)pd;
+          dsf[kw][qs * 4 + r] = (bf16_t)(p * (dpd - del4[r]));
+        }
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const bf16x8 dotf = tr_frag(dOt, STRIDE, 0, dt * 16, lane);
+      const bf16x8 qtf = tr_frag(Qt, STRIDE, 0, dt * 16, lane);
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        dv[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf[kw], dv[kw][dt], 0, 0, 0);
+        dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw], dk[kw][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) {
+    const int key = kbase + kw * 16 + i;
+    if (key >= a.Lk) continue;
+    bf16_t* dkp = a.dK + ((long)b * a.Lk + key) * a.lddk + h * HD + 4 * g;
+    bf16_t* dvp = a.dV + ((long)b * a.Lk + key) * a.lddv + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 wk, wv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        wk[r] = (bf16_t)(dk[kw][dt][r] * a.scale);
+        wv[r] = (bf16_t)dv[kw][dt][r];
+      }
+      *(bf16x4*)(dkp + dt * 16) = wk;
+      *(bf16x4*)(dvp + dt * 16) = wv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ export
+// Head-averaged (post-dropout when thr16 != 0) probabilities [B, Lq, Lk] from the saved LSE
+// (reference: need_weights=True path of nn.MultiheadAttention, average_attn_weights=True).
+// Inference/analysis only: plain VALU dot products, 8 query rows x 64 keys per block.
+template <int HD>
+__global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a) {
+  __shared__ float qs[8][HD];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, q0 = blockIdx.y * 8, key = blockIdx.x * 64 + tid;
+  const bool kin = key < a.Lk;
+  const bool pad = !kin || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  for (int h = 0; h < a.H; ++h) {
+    __syncthreads();
+    for (int id = tid; id < 8 * HD; id += 64) {
+      const int r = id / HD, e = id - r * HD;
+      const int q = min(q0 + r, a.Lq - 1);
+      qs[r][e] = (float)a.Q[((long)b * a.Lq + q) * a.ldq + h * HD + e];
+    }
+    __syncthreads();
+    float dot[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dot[r] = 0.f;
+    if (kin) {
+      const bf16_t* kp = a.K + ((long)b * a.Lk + key) * a.ldk + h * HD;
+      for (int c = 0; c < HD / 8; ++c) {
+        const bf16x8 kv = *(const bf16x8*)(kp + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float kf = (float)kv[j];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) dot[r] += kf * qs[r][c * 8 + j];
+        }
+      }
+    }
+    const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int q = min(q0 + r, a.Lq - 1);
+      float p = pad ? 0.f : __expf(dot[r] * a.scale - a.lse[((long)b * a.H + h) * a.Lq + q]);
+      if (a.thr16 != 0) p = keep16(key32, (uint32_t)q, (uint32_t)key, a.thr16) ? p * a.inv_keep : 0.f;
+      acc[r] += p;
+    }
+  }
+  if (kin) {
+    const float invH = 1.f / (float)a.H;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (q0 + r < a.Lq) a.probs[((long)b * a.Lq + q0 + r) * a.Lk + key] = acc[r] * invH;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static int check_common(const AttnArgs& a, int hd) {
+  HRIEMO_CHECK(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "attn: empty problem");
+  HRIEMO_CHECK(hd == 16 || hd == 32 || hd == 64 || hd == 96 || hd == 128, "attn: head_dim %d not built (16/32/64/96/128)", hd);
+  HRIEMO_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0, "attn: leading dims must be multiples of 8");
+  HRIEMO_CHECK(((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.K % 16) == 0 && ((uintptr_t)a.V % 16) == 0, "attn: unaligned Q/K/V");
+  return 0;
+}
+
+#define DISPATCH_HD(hd, CALL)               \
+  switch (hd) {                             \
+    case 16: { CALL(16); } break;           \
+    case 32: { CALL(32); } break;           \
+    case 64: { CALL(64); } break;           \
+    case 96: { CALL(96); } break;           \
+    case 128: { CALL(128); } break;         \
+  }
+
+static void fill_drop(AttnArgs& a, float p, uint64_t seed, uint32_t site, int b_offset) {
+  DropCfg d = make_drop(p, seed, site);
+  a.thr16 = d.thr16; a.inv_keep = d.inv_keep; a.seed = seed; a.site = site; a.b_offset = b_offset;
+}
+
+extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                               long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
+                               int Lk, int head_dim, float p_drop, unsigned long long seed, unsigned site,
+                               int b_offset, hipStream_t st) {
+  AttnArgs a = {};
+  a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.kpm = key_padding_mask; a.lse = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  a.scale = 1.0f / sqrtf((float)head_dim);
+  fill_drop(a, p_drop, seed, site, b_offset);
+  if (check_common(a, head_dim)) return 1;
+  HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: unaligned O");
+  hriemo_prof_begin(HP_ATTN_FWD, st);
+  if (Lq > 64) {
+#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 2>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  } else if (Lq > 16) {
+#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 1>), dim3((Lq + 63) / 64, B * H), dim3(256), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 1, 1>), dim3(1, B * H), dim3(64), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  }
+  HRIEMO_LAUNCH_CHECK("attn_fwd_kernel");
+  hriemo_prof_end(HP_ATTN_FWD, st, 4.0 * B * H * (double)Lq * Lk * head_dim);
+  return 0;
+}
+
+extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                               const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
+                               long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
+                               const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
+                               float p_drop, unsigned long long seed, unsigned site, int b_offset, hipStream_t st) {
+  AttnArgs a = {};
+  a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.dO = (const bf16_t*)dO; a.lddo = lddo;
+  a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
+  a.kpm = key_padding_mask; a.lse = (float*)lse; a.delta = delta; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  a.scale = 1.0f / sqrtf((float)head_dim);
+  fill_drop(a, p_drop, seed, site, b_offset);
+  if (check_common(a, head_dim)) return 1;
+  HRIEMO_CHECK(ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: bad leading dims");
+  HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
+                   ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0, "attn_bwd: unaligned operand");
+  hriemo_prof_begin(HP_ATTN_BWD_DQ, st);
+  if (Lq > 64) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  } else if (Lq > 16) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 1>), dim3((Lq + 63) / 64, B * H), dim3(256), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 1, 1>), dim3(1, B * H), dim3(64), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  }
+  HRIEMO_LAUNCH_CHECK("attn_bwd_dq_kernel");
+  hriemo_prof_end(HP_ATTN_BWD_DQ, st, 6.0 * B * H * (double)Lq * Lk * head_dim);
+  hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
+  if (Lk > 64) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2>), dim3((Lk + 127) / 128, B * H), dim3(256), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  } else if (Lk > 16) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1>), dim3((Lk + 63) / 64, B * H), dim3(256), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1>), dim3(1, B * H), dim3(64), 0, st, a)
+    DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  }
+  HRIEMO_LAUNCH_CHECK("attn_bwd_dkv_kernel");
+  hriemo_prof_end(HP_ATTN_BWD_DKV, st, 8.0 * B * H * (double)Lq * Lk * head_dim);
+  return 0;
+}
+
+extern "C" int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,
+                                 const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim,
+                                 float p_drop, unsigned long long seed, unsigned site, int b_offset, hipStream_t st) {
+  AttnArgs a = {};
+  a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)K;
+  a.ldq = ldq; a.ldk = ldk; a.ldv = ldk;
+  a.kpm = key_padding_mask; a.lse = (float*)lse; a.probs = probs; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
+  a.scale = 1.0f / sqrtf((float)head_dim);
+  fill_drop(a, p_drop, seed, site, b_offset);
+  if (check_common(a, head_dim)) return 1;
+#define CALL(HD) hipLaunchKernelGGL((attn_probs_kernel<HD>), dim3((Lk + 63) / 64, (Lq + 7) / 8, B), dim3(64), 0, st, a)
+  DISPATCH_HD(head_dim, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("attn_probs_kernel");
+  return 0;
+}

@@ -1,0 +1,92 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the HRI-EMO fusion path.
+// wave = 64 lanes everywhere; bf16 storage, fp32 arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+#define GLB_PTR(T) __attribute__((address_space(1))) T*
+
+// ---------------------------------------------------------------- error plumbing (host)
+void hriemo_set_error(const char* fmt, ...);
+#define HRIEMO_CHECK(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      hriemo_set_error(__VA_ARGS__);       \
+      return 1;                            \
+    }                                      \
+  } while (0)
+#define HRIEMO_LAUNCH_CHECK(name)                                         \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) {                                              \
+      hriemo_set_error("%s launch failed: %s", name, hipGetErrorString(e__)); \
+      return 2;                                                           \
+    }                                                                     \
+  } while (0)
+
+// optional per-kernel-class event timing (bench.py roofline leg); see prof.cpp
+enum { HP_GEMM_NT = 0, HP_GEMM_NN, HP_GEMM_TN, HP_ATTN_FWD, HP_ATTN_BWD_DQ, HP_ATTN_BWD_DKV, HP_ROWOPS, HP_NCLASS };
+void hriemo_prof_begin(int cls, hipStream_t s);
+void hriemo_prof_end(int cls, hipStream_t s, double work);
+
+// ---------------------------------------------------------------- wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------- dropout RNG
+// Counter hash (murmur3 finaliser) -- one 16-bit uniform per element, replayable in the
+// backward from (key, a, b) alone so no mask is ever stored.  key = site_key(seed, site, c).
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t site_key(uint64_t seed, uint32_t site, uint32_t c) {
+  uint32_t k = fmix32((uint32_t)seed ^ 0x9e3779b9u);
+  k = fmix32(k + (uint32_t)(seed >> 32) * 0x85ebca77u + site * 0x27d4eb2fu);
+  return fmix32(k + c * 0x165667b1u);
+}
+// true = element is kept.  thr16 = round(p * 65536): P(drop) = thr16 / 65536.
+__host__ __device__ __forceinline__ bool keep16(uint32_t key, uint32_t a, uint32_t b, uint32_t thr16) {
+  uint32_t x = fmix32(key + a * 0x9e3779b1u + b * 0x85ebca77u);
+  return (x >> 16) >= thr16;
+}
+
+struct DropCfg {
+  uint64_t seed;
+  uint32_t site;
+  uint32_t thr16;     // 0 => dropout off
+  float inv_keep;     // 1 / (1 - thr16/65536)
+};
+static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
+  DropCfg d;
+  d.seed = seed; d.site = site;
+  long t = (long)(p * 65536.0 + 0.5);
+  if (t < 0) t = 0;
+  if (t > 65535) t = 65535;
+  d.thr16 = (uint32_t)t;
+  d.inv_keep = (float)(1.0 / (1.0 - (double)t / 65536.0));
+  return d;
+}
+
+// ---------------------------------------------------------------- small vector helpers
+__device__ __forceinline__ void bf8_to_f32(const bf16x8& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+__device__ __forceinline__ bf16x8 f32_to_bf8(const float* f) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+  return v;
+}

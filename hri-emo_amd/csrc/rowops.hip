@@ -1,0 +1,748 @@
+// HBM-bound row kernels of the fusion path (one wave64 per [d]-row, 16-byte bf16 vectors, fp32 math):
+//   add_ln_fwd/bwd   y = LayerNorm(x + dropout(g))          cross_modal_block_tacfn.py:81,92,105,106,118,119
+//                                                          emotion_decoder.py:43,55,59
+//   ln_pool_fwd/bwd  LayerNorm + masked mean-pool           beta_gate_tacfn.py:6-24,79-84
+//   gate_* / fuse_*  gate input, sigmoid gate, gated fuse   beta_gate_tacfn.py:87-116
+//   colsum, cast, dropout, expand, rowdot                  bias grads, bf16 shadows, decoder glue
+// Column reductions (dgamma/dbeta/dbias, pooling) are two-stage (per-block partials in a caller
+// workspace, then a fixed-order reduce) so results are bitwise reproducible.
+#include "common.h"
+
+#define EPS_DEFAULT 1e-5f
+
+struct RowDrop { uint32_t key32, thr16; float inv_keep; };
+static RowDrop row_drop(float p, uint64_t seed, uint32_t site) {
+  DropCfg d = make_drop(p, seed, site);
+  RowDrop r; r.key32 = site_key(seed, site, 0u); r.thr16 = d.thr16; r.inv_keep = d.inv_keep;
+  return r;
+}
+
+// deterministic accumulate of per-wave column partials into an LDS row, wave by wave
+template <int NCH>
+__device__ __forceinline__ void block_colsum(float* lds_row, const float (&acc)[NCH][8], int nchunk, int lane, int wave, int nwave) {
+  for (int w = 0; w < nwave; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (w == 0) lds_row[ch * 8 + j] = acc[c][j];
+            else lds_row[ch * 8 + j] += acc[c][j];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ y = LN(x + drop(g))
+template <int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16_t* __restrict__ Y, float* __restrict__ mean_o,
+                                                         float* __restrict__ rstd_o, int M, int d, float eps, RowDrop dr,
+                                                         long row_offset) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  const float invd = 1.f / (float)d;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    float s[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float gf[8], xf[8];
+        bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
+        if (X != nullptr) bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), xf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float gv = gf[j];
+          if (dr.thr16 != 0) gv = keep16(dr.key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? gv * dr.inv_keep : 0.f;
+          s[c][j] = (X != nullptr ? xf[j] : 0.f) + gv;
+          sum += s[c][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[c][j] = 0.f;
+      }
+    }
+    const float mu = wave_sum(sum) * invd;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = s[c][j] - mu; sq += t * t; }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) * invd + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (s[c][j] - mu) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+        *(bf16x8*)(Y + row * d + ch * 8) = f32_to_bf8(o);
+      }
+    }
+    if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
+  }
+}
+
+// backward: dS (residual grad), dG = dS * mask/(1-p); column partials of dgamma, dbeta, dbias(=colsum dG)
+template <int NCH>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ G,
+                                                         const bf16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                         bf16_t* __restrict__ dX, bf16_t* __restrict__ dG,
+                                                         float* __restrict__ partials, int M, int d, RowDrop dr,
+                                                         long row_offset) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;   // [3][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = d >> 3;
+  const float invd = 1.f / (float)d;
+  float ag[NCH][8], ab[NCH][8], abias[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[c][j] = 0.f; ab[c][j] = 0.f; abias[c][j] = 0.f; }
+
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    const float mu = mean_i[row], rstd = rstd_i[row];
+    float xh[NCH][8], dyg[NCH][8];
+    bool kp[NCH][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float gf[8], xf[8], dyf[8];
+        bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
+        if (X != nullptr) bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), xf);
+        bf8_to_f32(*(const bf16x8*)(dY + row * d + ch * 8), dyf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float gv = gf[j];
+          kp[c][j] = true;
+          if (dr.thr16 != 0) {
+            kp[c][j] = keep16(dr.key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16);
+            gv = kp[c][j] ? gv * dr.inv_keep : 0.f;
+          }
+          const float sv = (X != nullptr ? xf[j] : 0.f) + gv;
+          xh[c][j] = (sv - mu) * rstd;
+          dyg[c][j] = dyf[j] * gamma[ch * 8 + j];
+          c1 += dyg[c][j];
+          c2 += dyg[c][j] * xh[c][j];
+          ag[c][j] += dyf[j] * xh[c][j];
+          ab[c][j] += dyf[j];
+        }
+      }
+    }
+    c1 = wave_sum(c1) * invd;
+    c2 = wave_sum(c2) * invd;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float ds[8], dg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ds[j] = rstd * (dyg[c][j] - c1 - xh[c][j] * c2);
+          dg[j] = kp[c][j] ? ds[j] * dr.inv_keep : 0.f;
+          if (dr.thr16 == 0) dg[j] = ds[j];
+          abias[c][j] += dg[j];
+        }
+        if (dX != nullptr) *(bf16x8*)(dX + row * d + ch * 8) = f32_to_bf8(ds);
+        if (dG != nullptr) *(bf16x8*)(dG + row * d + ch * 8) = f32_to_bf8(dg);
+      }
+    }
+  }
+  block_colsum<NCH>(red, ag, nchunk, lane, wave, 4);
+  block_colsum<NCH>(red + d, ab, nchunk, lane, wave, 4);
+  block_colsum<NCH>(red + 2 * d, abias, nchunk, lane, wave, 4);
+  float* out = partials + (long)blockIdx.x * 3 * d;
+  for (int t = threadIdx.x; t < 3 * d; t += 256) out[t] = red[t];
+}
+
+// out[col] (+)= sum_p partials[p][col]  -- fixed order
+__global__ void colreduce_kernel(const float* __restrict__ partials, long pstride, int np, float* __restrict__ out, int ncol,
+                                 float scale, int accumulate) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncol) return;
+  float s = 0.f;
+  for (int p = 0; p < np; ++p) s += partials[(long)p * pstride + col];
+  s *= scale;
+  out[col] = accumulate ? out[col] + s : s;
+}
+
+// column sums of a bf16 [M,N] matrix (bias grads): per-(slice) partials
+__global__ __launch_bounds__(64) void colsum_partial_kernel(const bf16_t* __restrict__ X, long ldx, int M, int N, int rows_per_slice,
+                                                            float* __restrict__ partials) {
+  const int lane = threadIdx.x;
+  const int ch = blockIdx.x * 64 + lane;
+  const int slice = blockIdx.y;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (ch * 8 < N) {
+    const int r0 = slice * rows_per_slice, r1 = min(M, r0 + rows_per_slice);
+    for (int r = r0; r < r1; ++r) {
+      float f[8];
+      bf8_to_f32(*(const bf16x8*)(X + (long)r * ldx + ch * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) partials[(long)slice * N + ch * 8 + j] = acc[j];
+  }
+}
+
+// ------------------------------------------------------------------ casts / dropout / expand / rowdot
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  const long nv = n >> 3;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+    const f32x4 a = *(const f32x4*)(src + v * 8), b = *(const f32x4*)(src + v * 8 + 4);
+    float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    *(bf16x8*)(dst + v * 8) = f32_to_bf8(f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = (bf16_t)src[(nv << 3) + threadIdx.x];
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long)gridDim.x * blockDim.x) dst[v] = (float)src[v];
+}
+
+__global__ void dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, long M, int N, RowDrop dr, long row_offset) {
+  const int nch = N >> 3;
+  const long nv = M * nch;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+    const long row = v / nch;
+    const int ch = (int)(v - row * nch);
+    float f[8];
+    bf8_to_f32(*(const bf16x8*)(X + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      f[j] = keep16(dr.key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? f[j] * dr.inv_keep : 0.f;
+    *(bf16x8*)(Y + v * 8) = f32_to_bf8(f);
+  }
+}
+
+// out[b][e][:] = q[e][:]   (emotion_decoder.py:127)
+__global__ void expand_rows_kernel(const float* __restrict__ q, bf16_t* __restrict__ out, int B, long n) {
+  const long total = (long)B * n;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) out[v] = (bf16_t)q[v % n];
+}
+
+// logits[r] = z[r,:] . w + b   (emotion_decoder.py:155)
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restrict__ Z, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ out, int M, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  float s = 0.f;
+  for (int ch = lane; ch < (d >> 3); ch += 64) {
+    float f[8];
+    bf8_to_f32(*(const bf16x8*)(Z + (long)row * d + ch * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += f[j] * w[ch * 8 + j];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s + (b != nullptr ? b[0] : 0.f);
+}
+// dZ[r,:] = dl[r]*w ; dw[e] = sum_r dl[r] z[r,e] ; db = sum_r dl[r]   (M is small: B*N_e)
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ w,
+                                                         bf16_t* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col < d) {
+    float acc = 0.f;
+    const float wc = w[col];
+    for (int r = 0; r < M; ++r) {
+      const float g = dl[r];
+      acc += g * (float)Z[(long)r * d + col];
+      dZ[(long)r * d + col] = (bf16_t)(g * wc);
+    }
+    dw[col] = acc;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < M; ++r) s += dl[r];
+    db[0] = s;
+  }
+}
+
+// ------------------------------------------------------------------ beta gate
+// LayerNorm every row of X[b, :, :]; write the first Lkeep rows; pooled partial sums over valid rows.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restrict__ X, const uint8_t* __restrict__ mask,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* __restrict__ Yn, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                          float* __restrict__ partials, int L, int Lkeep, int d, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = d >> 3;
+  const float invd = 1.f / (float)d;
+  float acc[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+  for (int l = chunk * 32 + wave; l < min(L, chunk * 32 + 32); l += 4) {
+    const long row = (long)b * L + l;
+    float s[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), s[c]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += s[c][j];
+      }
+    }
+    const float mu = wave_sum(sum) * invd;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < nchunk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = s[c][j] - mu; sq += t * t; }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) * invd + eps);
+    const bool valid = mask == nullptr || mask[(long)b * L + l] == 0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o[j] = (s[c][j] - mu) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+          if (valid) acc[c][j] += o[j];
+        }
+        if (l < Lkeep) *(bf16x8*)(Yn + ((long)b * Lkeep + l) * d + ch * 8) = f32_to_bf8(o);
+      }
+    }
+    if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
+  }
+  block_colsum<NCH>(red, acc, nchunk, lane, wave, 4);
+  float* out = partials + ((long)b * gridDim.x + chunk) * d;
+  for (int t = threadIdx.x; t < d; t += 256) out[t] = red[t];
+}
+
+// pooled means + gate input [a, t, |a-t|, a*t]  (beta_gate_tacfn.py:83-89)
+__global__ __launch_bounds__(256) void gate_input_kernel(const float* __restrict__ pa, int nca, const float* __restrict__ pt, int nct,
+                                                         const uint8_t* __restrict__ mask_a, const uint8_t* __restrict__ mask_t, int La, int Lt,
+                                                         int d, bf16_t* __restrict__ gin, float* __restrict__ a_pool, float* __restrict__ t_pool,
+                                                         float* __restrict__ cnt) {
+  __shared__ float sc[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    float ca = 0.f, ct = 0.f;
+    for (int l = tid; l < La; l += 64) ca += (mask_a == nullptr || mask_a[(long)b * La + l] == 0) ? 1.f : 0.f;
+    for (int l = tid; l < Lt; l += 64) ct += (mask_t == nullptr || mask_t[(long)b * Lt + l] == 0) ? 1.f : 0.f;
+    ca = wave_sum(ca); ct = wave_sum(ct);
+    if (tid == 0) { sc[0] = fmaxf(ca, 1.f); sc[1] = fmaxf(ct, 1.f); cnt[b * 2] = sc[0]; cnt[b * 2 + 1] = sc[1]; }
+  }
+  __syncthreads();
+  const float ia = 1.f / sc[0], it = 1.f / sc[1];
+  for (int c = tid; c < d; c += 256) {
+    float a = 0.f, t = 0.f;
+    for (int k = 0; k < nca; ++k) a += pa[((long)b * nca + k) * d + c];
+    for (int k = 0; k < nct; ++k) t += pt[((long)b * nct + k) * d + c];
+    a *= ia; t *= it;
+    a_pool[(long)b * d + c] = a; t_pool[(long)b * d + c] = t;
+    bf16_t* g = gin + (long)b * 4 * d;
+    g[c] = (bf16_t)a; g[d + c] = (bf16_t)t; g[2 * d + c] = (bf16_t)fabsf(a - t); g[3 * d + c] = (bf16_t)(a * t);
+  }
+}
+
+// w = sigmoid(pre), beta = mean_d(w)   (beta_gate_tacfn.py:92-95)
+__global__ __launch_bounds__(256) void sigmoid_beta_kernel(const float* __restrict__ pre, float* __restrict__ w, float* __restrict__ beta, int d) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int c = tid; c < d; c += 256) {
+    const float v = 1.f / (1.f + __expf(-pre[(long)b * d + c]));
+    w[(long)b * d + c] = v;
+    s += v;
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) beta[b] = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+}
+
+// h = w*a + (1-w)*t over [B, L, d]   (beta_gate_tacfn.py:113-116)
+__global__ void fuse_fwd_kernel(const float* __restrict__ w, const bf16_t* __restrict__ A, const bf16_t* __restrict__ T,
+                                bf16_t* __restrict__ H, int B, int L, int d) {
+  const int nch = d >> 3;
+  const long nv = (long)B * L * nch;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(v % nch);
+    const long b = v / ((long)L * nch);
+    float a[8], t[8], o[8];
+    bf8_to_f32(*(const bf16x8*)(A + v * 8), a);
+    bf8_to_f32(*(const bf16x8*)(T + v * 8), t);
+    const float* wp = w + b * d + ch * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = wp[j] * a[j] + (1.f - wp[j]) * t[j];
+    *(bf16x8*)(H + v * 8) = f32_to_bf8(o);
+  }
+}
+
+// dw partials: sum_l dH[b,l,:] * (A - T)[b,l,:]
+template <int NCH>
+__global__ __launch_bounds__(256) void fuse_bwd_dw_kernel(const bf16_t* __restrict__ dH, const bf16_t* __restrict__ A, const bf16_t* __restrict__ T,
+                                                          float* __restrict__ partials, int L, int d) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = d >> 3;
+  float acc[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[c][j] = 0.f;
+  for (int l = chunk * 32 + wave; l < min(L, chunk * 32 + 32); l += 4) {
+    const long row = (long)b * L + l;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float g[8], a[8], t[8];
+        bf8_to_f32(*(const bf16x8*)(dH + row * d + ch * 8), g);
+        bf8_to_f32(*(const bf16x8*)(A + row * d + ch * 8), a);
+        bf8_to_f32(*(const bf16x8*)(T + row * d + ch * 8), t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[c][j] += g[j] * (a[j] - t[j]);
+      }
+    }
+  }
+  block_colsum<NCH>(red, acc, nchunk, lane, wave, 4);
+  float* out = partials + ((long)b * gridDim.x + chunk) * d;
+  for (int t = threadIdx.x; t < d; t += 256) out[t] = red[t];
+}
+
+// dpre = (sum partials + dbeta/d) * w * (1-w)  -> bf16 for the gate-MLP backward GEMMs
+__global__ __launch_bounds__(256) void gate_dpre_kernel(const float* __restrict__ partials, int np, const float* __restrict__ dbeta,
+                                                        const float* __restrict__ w, bf16_t* __restrict__ dpre, int d) {
+  const int b = blockIdx.x;
+  const float db = dbeta != nullptr ? dbeta[b] / (float)d : 0.f;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float s = db;
+    for (int k = 0; k < np; ++k) s += partials[((long)b * np + k) * d + c];
+    const float wv = w[(long)b * d + c];
+    dpre[(long)b * d + c] = (bf16_t)(s * wv * (1.f - wv));
+  }
+}
+
+// d gate_in [B,4d] -> d a_pool, d t_pool (already divided by the valid counts)
+__global__ __launch_bounds__(256) void gate_input_bwd_kernel(const bf16_t* __restrict__ dgin, const float* __restrict__ a_pool,
+                                                             const float* __restrict__ t_pool, const float* __restrict__ cnt,
+                                                             float* __restrict__ da, float* __restrict__ dt, int d) {
+  const int b = blockIdx.x;
+  const float ia = 1.f / cnt[b * 2], it = 1.f / cnt[b * 2 + 1];
+  const bf16_t* g = dgin + (long)b * 4 * d;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float a = a_pool[(long)b * d + c], t = t_pool[(long)b * d + c];
+    const float g0 = (float)g[c], g1 = (float)g[d + c], g2 = (float)g[2 * d + c], g3 = (float)g[3 * d + c];
+    const float sg = (a > t) ? 1.f : ((a < t) ? -1.f : 0.f);
+    da[(long)b * d + c] = (g0 + sg * g2 + t * g3) * ia;
+    dt[(long)b * d + c] = (g1 - sg * g2 + a * g3) * it;
+  }
+}
+
+// backward of LayerNorm+pool+fuse-branch for one modality:
+//   dYn[l] = (l < Lf ? coef * dH[b,l] : 0) + (valid_l ? dpool[b] : 0),  coef = is_a ? w : 1-w ;  dX = LN'(dYn)
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ w, int is_a,
+                                                          const float* __restrict__ dpool, const uint8_t* __restrict__ mask,
+                                                          const bf16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          bf16_t* __restrict__ dX, float* __restrict__ partials, int L, int d) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;   // [2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = d >> 3;
+  const float invd = 1.f / (float)d;
+  float ag[NCH][8], ab[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[c][j] = 0.f; ab[c][j] = 0.f; }
+  for (int l = chunk * 32 + wave; l < min(L, chunk * 32 + 32); l += 4) {
+    const long row = (long)b * L + l;
+    const float mu = mean_i[row], rstd = rstd_i[row];
+    const bool valid = mask == nullptr || mask[row] == 0;
+    float xh[NCH][8], dyg[NCH][8];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float xf[8], gh[8];
+        bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), xf);
+        if (dH != nullptr && l < Lf) bf8_to_f32(*(const bf16x8*)(dH + ((long)b * Lf + l) * d + ch * 8), gh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int col = ch * 8 + j;
+          float dy = valid ? dpool[(long)b * d + col] : 0.f;
+          if (dH != nullptr && l < Lf) {
+            const float wv = w[(long)b * d + col];
+            dy += (is_a ? wv : 1.f - wv) * gh[j];
+          }
+          xh[c][j] = (xf[j] - mu) * rstd;
+          dyg[c][j] = dy * gamma[col];
+          c1 += dyg[c][j];
+          c2 += dyg[c][j] * xh[c][j];
+          ag[c][j] += dy * xh[c][j];
+          ab[c][j] += dy;
+        }
+      }
+    }
+    c1 = wave_sum(c1) * invd;
+    c2 = wave_sum(c2) * invd;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        float ds[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ds[j] = rstd * (dyg[c][j] - c1 - xh[c][j] * c2);
+        *(bf16x8*)(dX + row * d + ch * 8) = f32_to_bf8(ds);
+      }
+    }
+  }
+  block_colsum<NCH>(red, ag, nchunk, lane, wave, 4);
+  block_colsum<NCH>(red + d, ab, nchunk, lane, wave, 4);
+  float* out = partials + ((long)b * gridDim.x + chunk) * 2 * d;
+  for (int t = threadIdx.x; t < 2 * d; t += 256) out[t] = red[t];
+}
+
+// ================================================================== host entry points
+#define DISPATCH_NCH(d, CALL)                         \
+  {                                                   \
+    const int nch__ = ((d) / 8 + 63) / 64;            \
+    if (nch__ <= 1) { CALL(1); }                      \
+    else if (nch__ <= 2) { CALL(2); }                 \
+    else if (nch__ <= 4) { CALL(4); }                 \
+    else { CALL(8); }                                 \
+  }
+
+static int check_rows(int M, int d) {
+  HRIEMO_CHECK(M > 0 && d > 0, "rowops: empty problem");
+  HRIEMO_CHECK(d % 8 == 0 && d <= 4096, "rowops: d=%d must be a multiple of 8 and <= 4096", d);
+  return 0;
+}
+static int row_grid(int M, int cap) { int g = (M + 3) / 4; return g > cap ? cap : g; }
+
+extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
+                                 float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed, unsigned site,
+                                 long row_offset, hipStream_t st) {
+  if (check_rows(M, d)) return 1;
+  RowDrop dr = row_drop(p_drop, seed, site);
+  hriemo_prof_begin(HP_ROWOPS, st);
+#define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, gamma, beta, (bf16_t*)Y, mean, rstd, M, d, eps, dr, row_offset)
+  DISPATCH_NCH(d, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("add_ln_fwd_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (X ? 3.0 : 2.0) * M * d * 2);
+  return 0;
+}
+
+extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return (long)row_grid(M, 1024) * 3 * d * 4; }
+
+extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
+                                 const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
+                                 float p_drop, unsigned long long seed, unsigned site, long row_offset, float* workspace,
+                                 hipStream_t st) {
+  if (check_rows(M, d)) return 1;
+  HRIEMO_CHECK(workspace != nullptr, "add_ln_bwd: workspace required");
+  RowDrop dr = row_drop(p_drop, seed, site);
+  const int nb = row_grid(M, 1024);
+  hriemo_prof_begin(HP_ROWOPS, st);
+#define CALL(N) hipLaunchKernelGGL((add_ln_bwd_kernel<N>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, (const bf16_t*)X, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
+  DISPATCH_NCH(d, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("add_ln_bwd_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, 5.0 * M * d * 2);
+  const int g = (d + 255) / 256;
+  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace, (long)3 * d, nb, dgamma, d, 1.f, 0);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace + d, (long)3 * d, nb, dbeta, d, 1.f, 0);
+  if (dbias != nullptr)
+    hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace + 2 * d, (long)3 * d, nb, dbias, d, 1.f, 0);
+  HRIEMO_LAUNCH_CHECK("colreduce_kernel");
+  return 0;
+}
+
+static int colsum_slices(int M, int N) {
+  const int ncg = (N / 8 + 63) / 64;
+  int slices = 2048 / ncg;
+  if (slices > (M + 15) / 16) slices = (M + 15) / 16;
+  if (slices < 1) slices = 1;
+  return slices;
+}
+extern "C" long hriemo_colsum_workspace_bytes(int M, int N) { return (long)colsum_slices(M, N) * N * 4; }
+
+extern "C" int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int accumulate, float* workspace, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0, "colsum: bad shape M=%d N=%d ld=%ld", M, N, ldx);
+  HRIEMO_CHECK(workspace != nullptr, "colsum: workspace required");
+  const int ncg = (N / 8 + 63) / 64;
+  const int slices = colsum_slices(M, N);
+  const int rps = (M + slices - 1) / slices;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ncg, slices), dim3(64), 0, st, (const bf16_t*)X, ldx, M, N, rps, workspace);
+  hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, (long)N, slices, out, N, 1.f, accumulate);
+  HRIEMO_LAUNCH_CHECK("colsum");
+  return 0;
+}
+
+extern "C" int hriemo_cast_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
+  HRIEMO_CHECK(n > 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "cast: empty or unaligned");
+  long g = ((n >> 3) + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((int)g), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  HRIEMO_LAUNCH_CHECK("cast_f32_bf16_kernel");
+  return 0;
+}
+extern "C" int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t st) {
+  HRIEMO_CHECK(n > 0, "cast: empty");
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((int)g), dim3(256), 0, st, (const bf16_t*)src, dst, n);
+  HRIEMO_LAUNCH_CHECK("cast_bf16_f32_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed, unsigned site,
+                                   long row_offset, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && N > 0 && N % 8 == 0, "dropout: bad shape");
+  RowDrop dr = row_drop(p_drop, seed, site);
+  long g = (M * (N / 8) + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3((int)g), dim3(256), 0, st, (const bf16_t*)X, (bf16_t*)Y, M, N, dr, row_offset);
+  HRIEMO_LAUNCH_CHECK("dropout_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_expand_rows(const float* q, void* out, int B, long n, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && n > 0, "expand: empty");
+  long g = ((long)B * n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(expand_rows_kernel, dim3((int)g), dim3(256), 0, st, q, (bf16_t*)out, B, n);
+  HRIEMO_LAUNCH_CHECK("expand_rows_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_rowdot_fwd(const void* Z, const float* w, const float* b, float* out, int M, int d, hipStream_t st) {
+  if (check_rows(M, d)) return 1;
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)Z, w, b, out, M, d);
+  HRIEMO_LAUNCH_CHECK("rowdot_fwd_kernel");
+  return 0;
+}
+extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* w, void* dZ, float* dw, float* db, int M, int d,
+                                 hipStream_t st) {
+  if (check_rows(M, d)) return 1;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dl, (const bf16_t*)Z, w, (bf16_t*)dZ, dw, db, M, d);
+  HRIEMO_LAUNCH_CHECK("rowdot_bwd_kernel");
+  return 0;
+}
+
+// ---- beta gate ----
+extern "C" int hriemo_pool_chunks(int L) { return (L + 31) / 32; }
+
+extern "C" int hriemo_ln_pool_fwd(const void* X, const unsigned char* mask, const float* gamma, const float* beta, void* Yn,
+                                  float* mean, float* rstd, float* partials, int B, int L, int Lkeep, int d, float eps,
+                                  hipStream_t st) {
+  if (check_rows(B * L, d)) return 1;
+  HRIEMO_CHECK(Lkeep >= 0 && Lkeep <= L, "ln_pool_fwd: Lkeep=%d out of range (L=%d)", Lkeep, L);
+  const int nc = (L + 31) / 32;
+  hriemo_prof_begin(HP_ROWOPS, st);
+#define CALL(N) hipLaunchKernelGGL((ln_pool_fwd_kernel<N>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps)
+  DISPATCH_NCH(d, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("ln_pool_fwd_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, ((double)B * L + (double)B * Lkeep) * d * 2);
+  return 0;
+}
+
+extern "C" int hriemo_gate_input(const float* partials_a, const float* partials_t, const unsigned char* mask_a,
+                                 const unsigned char* mask_t, int B, int La, int Lt, int d, void* gate_in, float* a_pool,
+                                 float* t_pool, float* cnt, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && d > 0, "gate_input: empty");
+  hipLaunchKernelGGL(gate_input_kernel, dim3(B), dim3(256), 0, st, partials_a, (La + 31) / 32, partials_t, (Lt + 31) / 32, mask_a,
+                     mask_t, La, Lt, d, (bf16_t*)gate_in, a_pool, t_pool, cnt);
+  HRIEMO_LAUNCH_CHECK("gate_input_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_sigmoid_beta(const float* pre, float* w, float* beta, int B, int d, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && d > 0, "sigmoid_beta: empty");
+  hipLaunchKernelGGL(sigmoid_beta_kernel, dim3(B), dim3(256), 0, st, pre, w, beta, d);
+  HRIEMO_LAUNCH_CHECK("sigmoid_beta_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_fuse_fwd(const float* w, const void* A, const void* T, void* H, int B, int L, int d, hipStream_t st) {
+  if (check_rows(B * L, d)) return 1;
+  long g = ((long)B * L * (d / 8) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(fuse_fwd_kernel, dim3((int)g), dim3(256), 0, st, w, (const bf16_t*)A, (const bf16_t*)T, (bf16_t*)H, B, L, d);
+  HRIEMO_LAUNCH_CHECK("fuse_fwd_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, 3.0 * B * L * d * 2);
+  return 0;
+}
+
+extern "C" int hriemo_fuse_bwd_dw(const void* dH, const void* A, const void* T, float* partials, int B, int L, int d,
+                                  hipStream_t st) {
+  if (check_rows(B * L, d)) return 1;
+  const int nc = (L + 31) / 32;
+#define CALL(N) hipLaunchKernelGGL((fuse_bwd_dw_kernel<N>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)dH, (const bf16_t*)A, (const bf16_t*)T, partials, L, d)
+  DISPATCH_NCH(d, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("fuse_bwd_dw_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_gate_dpre(const float* partials, int L, const float* dbeta, const float* w, void* dpre, int B, int d,
+                                hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && d > 0, "gate_dpre: empty");
+  hipLaunchKernelGGL(gate_dpre_kernel, dim3(B), dim3(256), 0, st, partials, (L + 31) / 32, dbeta, w, (bf16_t*)dpre, d);
+  HRIEMO_LAUNCH_CHECK("gate_dpre_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, const float* t_pool, const float* cnt, float* da,
+                                     float* dt, int B, int d, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && d > 0, "gate_input_bwd: empty");
+  hipLaunchKernelGGL(gate_input_bwd_kernel, dim3(B), dim3(256), 0, st, (const bf16_t*)dgin, a_pool, t_pool, cnt, da, dt, d);
+  HRIEMO_LAUNCH_CHECK("gate_input_bwd_kernel");
+  return 0;
+}
+
+extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return (long)B * ((L + 31) / 32) * 2 * d * 4; }
+
+extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
+                                  const void* X, const float* gamma, const float* mean, const float* rstd, void* dX,
+                                  float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hipStream_t st) {
+  if (check_rows(B * L, d)) return 1;
+  HRIEMO_CHECK(workspace != nullptr && Lf <= L, "ln_pool_bwd: bad arguments");
+  const int nc = (L + 31) / 32;
+  hriemo_prof_begin(HP_ROWOPS, st);
+#define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), 2 * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
+  DISPATCH_NCH(d, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (2.0 * B * L + (double)B * Lf) * d * 2);
+  const int g = (d + 255) / 256;
+  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace, (long)2 * d, B * nc, dgamma, d, 1.f, 0);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace + d, (long)2 * d, B * nc, dbeta, d, 1.f, 0);
+  HRIEMO_LAUNCH_CHECK("colreduce_kernel");
+  return 0;
+}

@@ -1,0 +1,26 @@
+"""Drop-in for the reference's models/beta_gate_tacfn.py (masked_mean :6-24, BetaGate :27-118)."""
+import torch
+import torch.nn as nn
+
+from .. import _ops
+
+
+class BetaGate(nn.Module):
+    def __init__(self, d_model: int = 768, hidden_dim: int = 256):
+        super().__init__()
+        self.d_model = d_model
+        self.norm_a = nn.LayerNorm(d_model)
+        self.norm_t = nn.LayerNorm(d_model)
+        self.mlp = nn.Sequential(nn.Linear(d_model * 4, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, d_model))
+        self._sh = _ops.Shadows()
+
+    def forward(self, h_a, h_t, mask_a=None, mask_t=None):
+        out_dtype = h_a.dtype
+        h_a, h_t = _ops.to_bf16(h_a), _ops.to_bf16(h_t)
+        B, La, _ = h_a.shape
+        Lt = h_t.shape[1]
+        kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
+        h_fusion, beta = _ops.BetaGateFn.apply(h_a, h_t, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight,
+                                     self.norm_t.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
+                                     self.mlp[2].bias, self._sh, kpm_a, kpm_t)
+        return h_fusion.to(out_dtype), beta

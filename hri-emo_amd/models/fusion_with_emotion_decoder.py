@@ -1,0 +1,70 @@
+"""Drop-in for the reference's models/fusion_with_emotion_decoder.py (FusionWithEmotionDecoder :10-197)."""
+import torch
+import torch.nn as nn
+
+from .cross_modal_block_tacfn import CrossModalTransformer
+from .beta_gate_tacfn import BetaGate
+from .emotion_decoder import EmotionDecoder
+
+
+class FusionWithEmotionDecoder(nn.Module):
+    def __init__(self, d_model: int = 768, num_emotions: int = 4, n_heads: int = 8, num_layers_fusion: int = 2,
+                 num_layers_decoder: int = 2, beta_hidden: int = 256, dropout: float = 0.1):
+        super().__init__()
+        self.cross_modal = CrossModalTransformer(num_layers=num_layers_fusion, d_model=d_model, n_heads=n_heads,
+                                                 dropout=dropout)
+        self.beta_gate = BetaGate(d_model=d_model, hidden_dim=beta_hidden)
+        self.emotion_decoder = EmotionDecoder(d_model=d_model, num_emotions=num_emotions, n_heads=n_heads,
+                                              num_layers=num_layers_decoder, dropout=dropout, use_output_layer=True)
+
+    def set_batch_offset(self, offset: int):
+        """Global index of this shard's first utterance: keeps dropout masks independent of how the
+        batch is sharded across GPUs (hri_emo_amd.dp)."""
+        for m in self.modules():
+            if hasattr(m, "batch_offset"):
+                m.batch_offset = int(offset)
+
+    def _ensure_3d(self, x):
+        if x.dim() == 2:
+            return x.unsqueeze(1)
+        if x.dim() == 3:
+            return x
+        raise ValueError(f"Expected 2D or 3D tensor, got {x.shape}")
+
+    def _build_fused_mask(self, mask_a, mask_t, L_fused):
+        if mask_a is None and mask_t is None:
+            return None
+
+        def fit(m):
+            if m is None:
+                return None
+            if m.size(1) < L_fused:
+                pad = torch.ones(m.size(0), L_fused - m.size(1), dtype=torch.bool, device=m.device)
+                return torch.cat([m, pad], dim=1)
+            return m[:, :L_fused]
+
+        ma, mt = fit(mask_a), fit(mask_t)
+        if ma is None:
+            return mt
+        if mt is None:
+            return ma
+        return ma | mt
+
+    def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):
+        h_a, h_t = self._ensure_3d(h_a), self._ensure_3d(h_t)
+        out_dtype = h_a.dtype
+        # one cast at the boundary; everything between the sub-modules stays bf16 in HBM
+        h_a, h_t = h_a.to(torch.bfloat16), h_t.to(torch.bfloat16)
+        if return_attention:
+            h_a_tilde, h_t_tilde, encoder_attns = self.cross_modal(h_a, h_t, mask_a, mask_t, return_attention=True)
+        else:
+            h_a_tilde, h_t_tilde = self.cross_modal(h_a, h_t, mask_a, mask_t, return_attention=False)
+            encoder_attns = None
+        h_fusion, beta = self.beta_gate(h_a_tilde, h_t_tilde, mask_a, mask_t)
+        fused_mask = self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
+        if return_attention:
+            z, logits, decoder_attns = self.emotion_decoder(memory=h_fusion, memory_key_padding_mask=fused_mask,
+                                                            return_attention=True)
+            return logits, beta, z.to(out_dtype), {"encoder": encoder_attns, "decoder": decoder_attns}
+        z, logits = self.emotion_decoder(memory=h_fusion, memory_key_padding_mask=fused_mask, return_attention=False)
+        return logits, beta, z.to(out_dtype)

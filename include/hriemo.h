@@ -1,0 +1,124 @@
+/* hriemo.h -- C ABI of libhriemo.so: the MI355X (gfx950) kernels behind HRI-EMO's cross-modal fusion +
+ * beta-gate + emotion-decoder forward/backward path.
+ *
+ * The reference (Makiato1999/HRI-EMO) has no FFI layer: every FLOP of this path is a stock torch.nn
+ * call inside models/ (SURVEY.md section 8b).  Each entry point below therefore names the reference
+ * nn.Module arithmetic it replaces (file:line under the reference tree); the Python mirror of the
+ * reference's nn.Module API (hri-emo_amd/models/) binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (outputs and
+ *    workspaces included); nothing is allocated, freed or synchronised inside (graph-capturable);
+ *  - activations are bf16 (uint16 storage) row-major with an explicit leading dimension in ELEMENTS;
+ *    statistics, parameters' masters, gradients of parameters are fp32;
+ *  - masks are uint8 [B, L], 1 = PAD (the reference's key_padding_mask convention);
+ *  - dropout is replayed from (seed, site, row/col) -- the backward takes the same triple, no mask is
+ *    stored; p_drop = 0 disables it;  b_offset / row_offset = global index of the first utterance/row
+ *    of this shard so masks do not depend on how the batch is sharded over GPUs;
+ *  - `stream` is a hipStream_t; return 0 = ok, otherwise hriemo_last_error() explains.
+ */
+#ifndef HRIEMO_H_
+#define HRIEMO_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hriemo_stream_t;
+
+const char* hriemo_last_error(void);
+int hriemo_abi_version(void);
+
+/* ---- GEMM: every nn.Linear / packed in-projection / out-projection on the path and their backward.
+ * C[M,N] = opA(A) . opB(B) (+bias) with fp32 accumulation on MFMA 16x16x32 bf16.
+ *   ta=0: A is [M,K] (K contiguous)      ta=1: A is [K,M] (dW = dY^T . X)
+ *   tb=0: B is [N,K] (weight layout)     tb=1: B is [K,N] (dX = dY . W)
+ * c_is_f32: 0 -> bf16 C, 1 -> fp32 C (weight gradients; split-K through `workspace`).
+ * epilogue (bf16 C only): 0 none, 1 ReLU, 2 multiply by (aux > 0) (ReLU backward), 3 add aux
+ *   (fuses the residual-branch gradient into the dX GEMM).
+ * Replaces: F.linear in nn.MultiheadAttention in-proj/out-proj (models/cross_modal_block_tacfn.py:24-40,
+ * 74-117; models/emotion_decoder.py:14,20,42-54), ffn_a/ffn_t (cross_modal_block_tacfn.py:43-52,106,119),
+ * linear1/linear2 (emotion_decoder.py:25-27,58), gate MLP (models/beta_gate_tacfn.py:62-66,92). */
+int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                     void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
+                     long ldaux, int accumulate, float* workspace, long workspace_bytes, hriemo_stream_t stream);
+
+/* ---- attention core: softmax(QK^T/sqrt(hd) + mask) -> dropout -> .V per (batch, head), flash style.
+ * Q/K/V/O/dX are read/written in place inside the projection buffers: element (b, l, h, e) of X is
+ * X[(b*L + l)*ldx + h*head_dim + e].  lse [B,H,Lq] (natural log) is written by fwd, read by bwd/probs;
+ * delta [B,H,Lq] is bwd scratch.  Replaces the body of nn.MultiheadAttention.forward between the
+ * projections (cross_modal_block_tacfn.py:74-80,85-91,98-104,111-117; emotion_decoder.py:42,48-54). */
+int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
+                    const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
+                    float p_drop, unsigned long long seed, unsigned site, int b_offset, hriemo_stream_t stream);
+int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O, long ldo,
+                    const void* dO, long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
+                    const unsigned char* key_padding_mask, const float* lse, float* delta, int B, int H, int Lq,
+                    int Lk, int head_dim, float p_drop, unsigned long long seed, unsigned site, int b_offset,
+                    hriemo_stream_t stream);
+/* head-averaged attention probabilities [B,Lq,Lk] fp32 (need_weights=True; return_attention path,
+ * cross_modal_block_tacfn.py:70-125, emotion_decoder.py:48-64) */
+int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,
+                      const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, float p_drop,
+                      unsigned long long seed, unsigned site, int b_offset, hriemo_stream_t stream);
+
+/* ---- y = LayerNorm(x + dropout(g)), eps, affine (X may be NULL: plain LayerNorm of g).
+ * Replaces norm(h + self.dropout(sub(h))) (cross_modal_block_tacfn.py:81,92,105,106,118,119;
+ * emotion_decoder.py:43,55,59).  bwd writes dX (residual branch), dG (sub-layer branch, dropout mask
+ * applied) and the column sums dgamma, dbeta, dbias (= colsum dG, the producing Linear's bias grad). */
+int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
+                      float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed, unsigned site,
+                      long row_offset, hriemo_stream_t stream);
+long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
+int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
+                      const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
+                      float p_drop, unsigned long long seed, unsigned site, long row_offset, float* workspace,
+                      hriemo_stream_t stream);
+
+/* ---- small glue on the path */
+long hriemo_colsum_workspace_bytes(int M, int N);
+int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int accumulate, float* workspace,
+                       hriemo_stream_t stream);                                   /* bias gradients */
+int hriemo_cast_f32_to_bf16(const float* src, void* dst, long n, hriemo_stream_t stream);   /* bf16 shadows */
+int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hriemo_stream_t stream);
+int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed, unsigned site,
+                        long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
+int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
+int hriemo_rowdot_fwd(const void* Z, const float* w, const float* b, float* out, int M, int d,
+                      hriemo_stream_t stream);                                     /* emotion_decoder.py:155 */
+int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* w, void* dZ, float* dw, float* db, int M, int d,
+                      hriemo_stream_t stream);
+
+/* ---- beta gate (models/beta_gate_tacfn.py:68-118): LayerNorm + masked mean-pool (:6-24,79-84),
+ * gate input [a,t,|a-t|,a*t] (:87-89), w = sigmoid(MLP), beta = mean(w) (:92-95), fuse over the first
+ * L positions (:98-116).  partials buffers are [B, hriemo_pool_chunks(L), d] fp32. */
+int hriemo_pool_chunks(int L);
+int hriemo_ln_pool_fwd(const void* X, const unsigned char* mask, const float* gamma, const float* beta, void* Yn,
+                       float* mean, float* rstd, float* partials, int B, int L, int Lkeep, int d, float eps,
+                       hriemo_stream_t stream);
+int hriemo_gate_input(const float* partials_a, const float* partials_t, const unsigned char* mask_a,
+                      const unsigned char* mask_t, int B, int La, int Lt, int d, void* gate_in, float* a_pool,
+                      float* t_pool, float* cnt, hriemo_stream_t stream);
+int hriemo_sigmoid_beta(const float* pre, float* w, float* beta, int B, int d, hriemo_stream_t stream);
+int hriemo_fuse_fwd(const float* w, const void* A, const void* T, void* H, int B, int L, int d, hriemo_stream_t stream);
+int hriemo_fuse_bwd_dw(const void* dH, const void* A, const void* T, float* partials, int B, int L, int d,
+                       hriemo_stream_t stream);
+int hriemo_gate_dpre(const float* partials, int L, const float* dbeta, const float* w, void* dpre, int B, int d,
+                     hriemo_stream_t stream);
+int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, const float* t_pool, const float* cnt, float* da,
+                          float* dt, int B, int d, hriemo_stream_t stream);
+long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
+int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
+                       const void* X, const float* gamma, const float* mean, const float* rstd, void* dX,
+                       float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hriemo_stream_t stream);
+
+/* ---- per-kernel-class HIP-event timing on the launch stream (bench.py roofline leg) */
+int hriemo_prof_enable(int on);
+int hriemo_prof_nclass(void);
+const char* hriemo_prof_name(int cls);
+int hriemo_prof_collect(int cls, double* ms_total, long* launches, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRIEMO_H_ */

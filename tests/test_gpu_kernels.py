@@ -1,0 +1,203 @@
+"""GPU suite, kernel level: each C-ABI entry point against plain torch fp32 math on the same inputs.
+GEMMs use small-integer operands so every layout/tail/epilogue case must match EXACTLY (a transposed or
+permuted fragment cannot hide); attention / LayerNorm kernels are compared in fp32 with the tolerance a
+bf16 result allows (stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import hashrng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import hri_emo_amd  # noqa: F401
+    from hri_emo_amd import _ops
+    return _ops
+
+
+def ints(shape, lo=-3, hi=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+GEMM_SHAPES = [(256, 256, 128), (200, 136, 96), (128, 384, 64), (1024, 768, 768), (64, 256, 3072), (37 * 8, 8, 32),
+               (130, 2304, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_exact(ops, M, N, K):
+    A, W, b = ints((M, K), seed=1), ints((N, K), seed=2), ints((N,), seed=3)
+    ref = A @ W.t() + b
+    y = ops.linear_fwd(A.cuda().bfloat16(), W.cuda().bfloat16(), b.cuda())
+    assert torch.equal(y.float().cpu(), ref.bfloat16().float())
+    yr = ops.linear_fwd(A.cuda().bfloat16(), W.cuda().bfloat16(), b.cuda(), relu=True)
+    assert torch.equal(yr.float().cpu(), ref.clamp(min=0).bfloat16().float())
+    yf = ops.linear_fwd(A.cuda().bfloat16(), W.cuda().bfloat16(), b.cuda(), out_f32=True)
+    assert torch.equal(yf.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nn_exact_with_epilogues(ops, M, N, K):
+    # dX[M,K] = dY[M,N] . W[N,K]
+    dY, W = ints((M, N), seed=4), ints((N, K), seed=5)
+    aux = ints((M, K), seed=6)
+    ref = dY @ W
+    dx = ops.linear_dx(dY.cuda().bfloat16(), W.cuda().bfloat16())
+    assert torch.equal(dx.float().cpu(), ref.bfloat16().float())
+    dx2 = ops.linear_dx(dY.cuda().bfloat16(), W.cuda().bfloat16(), epi=2, aux=aux.cuda().bfloat16())
+    assert torch.equal(dx2.float().cpu(), (ref * (aux > 0)).bfloat16().float())
+    dx3 = ops.linear_dx(dY.cuda().bfloat16(), W.cuda().bfloat16(), epi=3, aux=aux.cuda().bfloat16())
+    assert torch.equal(dx3.float().cpu(), (ref + aux).bfloat16().float())
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(4096, 768, 768), (32, 128, 512)])
+def test_gemm_tn_exact_splitk(ops, M, N, K):
+    # dW[N,K] = dY[M,N]^T . X[M,K]  (reduction over M rows; split-K when M is large)
+    dY, X = ints((M, N), -2, 3, seed=7), ints((M, K), -2, 3, seed=8)
+    ref = dY.t() @ X
+    out = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    ops.linear_dw(dY.cuda().bfloat16(), X.cuda().bfloat16(), out)
+    assert torch.equal(out.cpu(), ref)
+    # strided views: column slices of wider buffers, row slice of the output
+    wide = torch.zeros((M, N + 16), dtype=torch.bfloat16, device="cuda")
+    wide[:, 8:8 + N] = dY.cuda().bfloat16()
+    big = torch.zeros((N + 8, K), dtype=torch.float32, device="cuda")
+    ops.linear_dw(wide[:, 8:8 + N], X.cuda().bfloat16(), big[8:])
+    assert torch.equal(big[8:].cpu(), ref) and float(big[:8].abs().max()) == 0.0
+
+
+def test_colsum_and_cast(ops):
+    X = ints((1000, 264), seed=9)
+    out = torch.empty(264, dtype=torch.float32, device="cuda")
+    ops.colsum(X.cuda().bfloat16(), out)
+    assert torch.equal(out.cpu(), X.sum(0))
+    p = torch.nn.Parameter(torch.randn(77, 13).cuda())
+    sh = ops.Shadows()
+    assert torch.equal(sh.get(p), p.detach().bfloat16())
+    with torch.no_grad():
+        p.add_(1.0)
+    assert torch.equal(sh.get(p), p.detach().bfloat16())
+
+
+# ------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, kpm, keep, inv_keep):
+    """q [B,H,Lq,hd] etc. fp32 (autograd-capable); keep [B,H,Lq,Lk] bool or None"""
+    hd = q.shape[-1]
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    pd = p if keep is None else p * keep * inv_keep
+    return pd @ v, torch.logsumexp(s, dim=-1), pd
+
+
+ATTN_CASES = [  # B, H, Lq, Lk, hd, masked, p
+    (2, 2, 6, 6, 16, False, 0.0),
+    (2, 8, 6, 20, 96, True, 0.0),
+    (2, 8, 48, 20, 96, True, 0.0),
+    (2, 8, 20, 48, 96, True, 0.1),
+    (1, 4, 130, 70, 64, True, 0.0),
+    (2, 8, 400, 128, 96, True, 0.1),
+    (2, 8, 128, 400, 96, False, 0.0),
+    (3, 8, 32, 16, 16, True, 0.1),
+    (1, 2, 200, 200, 128, False, 0.0),
+    (1, 4, 50, 1000, 32, True, 0.0),
+]
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,masked,p", ATTN_CASES)
+def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
+    g = torch.Generator().manual_seed(100 + Lq + Lk)
+    d = H * hd
+    # projections laid out like the real buffers: q in [B*Lq, d], kv packed [B*Lk, 2d]
+    qb = (torch.randn(B * Lq, d, generator=g) * 1.5).bfloat16()
+    kvb = torch.randn(B * Lk, 2 * d, generator=g).bfloat16()
+    dob = torch.randn(B * Lq, d, generator=g).bfloat16()
+    kpm = None
+    if masked:
+        lens = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+        kpm = torch.arange(Lk)[None, :] >= lens[:, None]
+    seed, site, boff = 1234567890123, 40, 5
+    keep = None
+    if p > 0:
+        keep = torch.from_numpy(hashrng.attn_mask(seed, site, B, H, Lq, Lk, p, boff)).float()
+    q = qb.float().view(B, Lq, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    k = kvb[:, :d].float().contiguous().view(B, Lk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    v = kvb[:, d:].float().contiguous().view(B, Lk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    o_ref, lse_ref, pd_ref = ref_attention(q, k, v, kpm, keep, hashrng.inv_keep(p))
+    o_ref2 = o_ref.transpose(1, 2).reshape(B * Lq, d)
+    o_ref2.backward(dob.float())
+
+    qd, kvd, dod = qb.cuda(), kvb.cuda(), dob.cuda()
+    kpm_d = kpm.cuda().view(torch.uint8) if kpm is not None else None
+    o, lse = ops.attn_fwd(qd, kvd[:, :d], kvd[:, d:], B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff)
+    tol = 2e-2     # bf16 P and bf16 O: ~2^-8 relative on O(1) values
+    assert (o.float().cpu() - o_ref2.detach()).abs().max() <= tol * max(1.0, o_ref2.abs().max().item())
+    assert (lse.cpu() - lse_ref.detach()).abs().max() <= 2e-3 * max(1.0, lse_ref.abs().max().item())
+
+    probs = ops.attn_probs(qd, kvd[:, :d], B, H, Lq, Lk, hd, kpm_d, lse, p, seed, site, boff)
+    assert (probs.cpu() - pd_ref.detach().mean(1)).abs().max() <= 5e-3
+    if kpm is not None:
+        assert float(probs.cpu()[kpm[:, None, :].expand(B, Lq, Lk)].abs().max()) == 0.0
+
+    dq = torch.empty_like(qd)
+    dkv = torch.empty_like(kvd)
+    ops.attn_bwd(qd, kvd[:, :d], kvd[:, d:], o, dod, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm_d, p, seed,
+                 site, boff)
+    dq_ref = q.grad.transpose(1, 2).reshape(B * Lq, d)
+    dk_ref = k.grad.transpose(1, 2).reshape(B * Lk, d)
+    dv_ref = v.grad.transpose(1, 2).reshape(B * Lk, d)
+    for name, got, ref in (("dq", dq, dq_ref), ("dk", dkv[:, :d], dk_ref), ("dv", dkv[:, d:], dv_ref)):
+        err = (got.float().cpu() - ref).abs().max().item()
+        assert err <= 3e-2 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+
+
+def test_attention_all_pad_row_is_nan(ops):
+    B, H, L, hd = 2, 2, 8, 16
+    d = H * hd
+    q = torch.randn(B * L, d).bfloat16().cuda()
+    kv = torch.randn(B * L, 2 * d).bfloat16().cuda()
+    kpm = torch.zeros(B, L, dtype=torch.bool)
+    kpm[1, :] = True
+    o, lse = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, L, L, hd, kpm.cuda().view(torch.uint8), 0.0, 0, 0, 0)
+    o = o.float().cpu().view(B, L, d)
+    assert torch.isnan(o[1]).all() and not torch.isnan(o[0]).any()
+
+
+# ------------------------------------------------------------------------------------------- add + LN
+@pytest.mark.parametrize("M,d,p,resid", [(37, 128, 0.0, True), (300, 768, 0.1, True), (64, 768, 0.3, False),
+                                         (10, 1024, 0.1, True), (9, 2048, 0.0, True)])
+def test_add_ln_fwd_bwd(ops, M, d, p, resid):
+    g = torch.Generator().manual_seed(7 + M)
+    G = torch.randn(M, d, generator=g).bfloat16()
+    X = torch.randn(M, d, generator=g).bfloat16() if resid else None
+    gamma = (1 + 0.1 * torch.randn(d, generator=g))
+    beta = 0.1 * torch.randn(d, generator=g)
+    dY = torch.randn(M, d, generator=g).bfloat16()
+    seed, site, roff = 987654321, 12, 1000
+    keep = torch.from_numpy(hashrng.rows_mask(seed, site, M, d, p, roff)).float() if p > 0 else torch.ones(M, d)
+    ik = hashrng.inv_keep(p)
+    Gf = G.float().requires_grad_(True)
+    Xf = X.float().requires_grad_(True) if resid else None
+    gam, bet = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    s = Gf * keep * ik + (Xf if resid else 0)
+    y_ref = torch.nn.functional.layer_norm(s, (d,), gam, bet, 1e-5)
+    y_ref.backward(dY.float())
+
+    y, mean, rstd = ops.add_ln_fwd(G.cuda(), X.cuda() if resid else None, gamma.cuda(), beta.cuda(), p, seed, site, roff)
+    assert (y.float().cpu() - y_ref.detach()).abs().max() <= 2e-2      # bf16 output of O(1..4) values
+    assert (mean.cpu() - s.detach().mean(-1)).abs().max() <= 1e-5
+    dx, dg, dgam, dbet, dbias = ops.add_ln_bwd(dY.cuda(), G.cuda(), X.cuda() if resid else None, gamma.cuda(), mean, rstd,
+                                               p, seed, site, roff)
+    assert (dg.float().cpu() - Gf.grad).abs().max() <= 2e-2 * max(1.0, Gf.grad.abs().max().item())
+    if resid:
+        assert (dx.float().cpu() - Xf.grad).abs().max() <= 2e-2 * max(1.0, Xf.grad.abs().max().item())
+    assert (dgam.cpu() - gam.grad).abs().max() <= 2e-3 * max(1.0, gam.grad.abs().max().item())
+    assert (dbet.cpu() - bet.grad).abs().max() <= 2e-3 * max(1.0, bet.grad.abs().max().item())
+    assert (dbias.cpu() - Gf.grad.sum(0)).abs().max() <= 2e-2 * max(1.0, Gf.grad.sum(0).abs().max().item())
