@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/sec, fwd+bwd, of FusionWithEmotionDecoder on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path over one batch of synthetic utterances already resident in HBM:
+forward (train mode, dropout 0.1) -> BCEWithLogits - 0.01*beta-reg -> backward -> (N>1) gradient all-reduce
+over RCCL.  N=1 workload = BASELINE.json configs[1]: d=768, T_a=400, T_t=128, N_e=6, batch 64, bf16.
+For N>1 launch with torch.distributed.run (one rank per GPU); per-GPU batch stays 64 (weak scaling).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed on the launch stream inside
+libhriemo.so) and, at N=1, `cpu_baseline` (the CPU oracle timed on this box's host cores, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CFG = dict(d_model=768, num_emotions=6, n_heads=8, num_layers_fusion=2, num_layers_decoder=2, beta_hidden=256,
+           dropout=0.1)
+T_A, T_T = 400, 128
+FLOP_PER_UTT_FWD_BWD = 65.378e9           # SURVEY.md 8(d), closed form == FlopCounterMode
+PEAK_BF16_TFLOPS = 2500.0                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synth(B, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    h_a = torch.randn(B, T_A, CFG["d_model"], generator=g).to(device=device, dtype=torch.bfloat16)
+    h_t = torch.randn(B, T_T, CFG["d_model"], generator=g).to(device=device, dtype=torch.bfloat16)
+    m_a = torch.zeros(B, T_A, dtype=torch.bool, device=device)      # all-False masks, as the reference's tests
+    m_t = torch.zeros(B, T_T, dtype=torch.bool, device=device)
+    y = (torch.rand(B, CFG["num_emotions"], generator=g) < 0.3).float().to(device)
+    return h_a, h_t, m_a, m_t, y
+
+
+def cpu_baseline():
+    """CPU oracle (fp32, train mode, dropout 0.1), same shapes, B=8, 1 warm-up + 3 timed steps."""
+    from oracle import hri_emo_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    m = O.FusionWithEmotionDecoder(**CFG).train()
+    B = 8
+    g = torch.Generator().manual_seed(1234)
+    h_a, h_t = torch.randn(B, T_A, CFG["d_model"], generator=g), torch.randn(B, T_T, CFG["d_model"], generator=g)
+    m_a, m_t = torch.zeros(B, T_A, dtype=torch.bool), torch.zeros(B, T_T, dtype=torch.bool)
+    y = (torch.rand(B, CFG["num_emotions"], generator=g) < 0.3).float()
+    times = []
+    for i in range(4):
+        t0 = time.perf_counter()
+        logits, beta, _ = m(h_a, h_t, m_a, m_t)
+        O.train_step_loss(logits, beta, y).backward()
+        m.zero_grad()
+        if i:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    return {"value": round(B / times[len(times) // 2], 3), "unit": "utterances/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"CPU oracle fp32 train-mode fwd+bwd, B={B}, d=768 T_a=400 T_t=128 N_e=6, "
+                                      f"median of 3 steps after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import hri_emo_amd as H
+    from hri_emo_amd import _lib
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+
+    torch.manual_seed(1234)                       # same weights and same dropout-seed stream on every rank
+    model = H.FusionWithEmotionDecoder(**CFG).to(device).train()
+    dp = DataParallelStep(model, fusion_step_loss)
+    B = a.batch_per_gpu
+    dp.set_global_batch(B * world)
+    batch = synth(B, rank, device)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        dp.step(*batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dp.step(*batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / a.steps * 1e3
+    value = B * world / (ms * 1e-3)
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        L = _lib.lib()
+        L.hriemo_prof_enable(1)
+        nprof = min(a.steps, 5)
+        for _ in range(nprof):
+            dp.step(*batch)
+        torch.cuda.synchronize()
+        rows = []
+        for c in range(L.hriemo_prof_nclass()):
+            msum, n, work = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+            L.hriemo_prof_collect(c, ctypes.byref(msum), ctypes.byref(n), ctypes.byref(work))
+            rows.append((L.hriemo_prof_name(c).decode(), msum.value, n.value, work.value))
+        L.hriemo_prof_enable(0)
+        rows.sort(key=lambda r: -r[1])
+        name, msum, n, work = rows[0]                      # dominant kernel class by device time
+        avg_ms = msum / max(n, 1)
+        achieved = work / max(n, 1) / (avg_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // nprof,
+                "device_ms_per_step_by_class": {r[0]: round(r[1] / nprof, 3) for r in rows}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {"metric": "utterances/sec fwd+bwd, d=768 T_a=400 T_t=128 N_e=6", "value": round(value, 1),
+               "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "FusionWithEmotionDecoder fwd+bwd (train mode, dropout 0.1), d=768 T_a=400 "
+                                      "T_t=128 N_e=6 H=8, 2 fusion + 2 decoder layers, all-False masks",
+                          "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}",
+                          "grad_allreduce": "fp32 flat buckets 32MiB, RCCL" if world > 1 else "none"},
+               "model_tflops": round(value * FLOP_PER_UTT_FWD_BWD / 1e12, 1),
+               "model_mfma_frac": round(value * FLOP_PER_UTT_FWD_BWD / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

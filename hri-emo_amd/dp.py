@@ -1,0 +1,120 @@
+"""Data-parallel driver for the fusion path: one process per GPU, utterances sharded contiguously across
+ranks, ONE exchange step per iteration -- a sum/avg all-reduce of the parameter gradients (RCCL over xGMI
+when the backend is "nccl"; gloo on CPU for tests).  The reference has no distributed code;
+the contract here is "N-rank step on shards == 1-rank step on the concatenated batch".
+
+MI355X-first layout: every parameter gradient is a VIEW into one flat fp32 buffer, ordered in reverse
+parameter order (the order backward produces them: decoder first, fusion layer 0 last).  Buckets are
+contiguous slices of that buffer, so a bucket is all-reduced in place -- no flatten/unflatten copies -- and
+is launched from a post-accumulate-grad hook as soon as its last gradient has been written, overlapping the
+collective with the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s), so few large buckets
+(default 32 MiB) beat many small ones.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        order = list(reversed(self.params))
+        total = sum(p.numel() for p in order)
+        dev = order[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets = []           # (start, end, n_params)
+        self._bucket_of = {}
+        off, b_start, b_n = 0, 0, 0
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += n
+            b_n += 1
+            if (off - b_start) * 4 >= bucket_bytes:
+                self.buckets.append((b_start, off, b_n))
+                b_start, b_n = off, 0
+        if b_n:
+            self.buckets.append((b_start, off, b_n))
+        self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._hooks = []
+        if overlap and self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -- hooks ---------------------------------------------------------------------------------
+    def _launch(self, bi):
+        s, e, _ = self.buckets[bi]
+        self._launched[bi] = True
+        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[id(p)]
+        self._pending[bi] += 1
+        if self._pending[bi] == self.buckets[bi][2] and not self._launched[bi]:
+            self._launch(bi)
+
+    # -- per-step API --------------------------------------------------------------------------
+    def _rebind(self):
+        off = 0
+        for p in reversed(self.params):
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * 4:
+                p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero_grad(self):
+        self.flat.zero_()
+        self._rebind()                   # keep the views even if someone set grads to None
+
+    def finish(self):
+        """Complete the gradient exchange of this step and average over ranks."""
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                if not self._launched[bi]:          # no hooks, or a parameter got no gradient this step
+                    self._launch(bi)
+            for w in self._works:
+                w.wait()
+            self._works = []
+            self._pending = [0] * len(self.buckets)
+            self._launched = [False] * len(self.buckets)
+            self.flat.mul_(1.0 / self.world)
+
+    def grad_norm(self):
+        return self.flat.norm()
+
+
+def shard_bounds(global_batch, rank, world):
+    """Contiguous shard [lo, hi) of rank `rank` (rank r gets utterances [r*B/W, (r+1)*B/W))."""
+    if global_batch % world != 0:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+class DataParallelStep:
+    """fwd -> loss -> bwd -> gradient all-reduce for one shard; mirrors the order of operations of
+    train_one_epoch (scripts/fusion/train_fusion_seq_level_decoder.py:310-334) minus the optimizer."""
+
+    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True):
+        self.model, self.loss_fn = model, loss_fn
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap)
+
+    def set_global_batch(self, global_batch):
+        lo, hi = shard_bounds(global_batch, self.rank, self.world)
+        if hasattr(self.model, "set_batch_offset"):
+            self.model.set_batch_offset(lo)
+        return lo, hi
+
+    def step(self, h_a, h_t, m_a, m_t, y):
+        self.buckets.zero_grad()
+        logits, beta, _ = self.model(h_a, h_t, m_a, m_t)
+        loss = self.loss_fn(logits, beta, y)
+        loss.backward()
+        self.buckets.finish()
+        return loss.detach()
