@@ -169,15 +169,43 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
   for (int t = threadIdx.x; t < 3 * d; t += 256) out[t] = red[t];
 }
 
-// out[col] (+)= sum_p partials[p][col]  -- fixed order
-__global__ void colreduce_kernel(const float* __restrict__ partials, long pstride, int np, float* __restrict__ out, int ncol,
-                                 float scale, int accumulate) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= ncol) return;
+// out[g][col] (+)= scale * sum_{p in group g} partials[p][col]  -- fixed order, two-level tree:
+// block = 32 columns x 8 row-lanes; blockIdx.y = group of `per_group` partials (pass 1 writes one row
+// per group into a scratch, pass 2 folds those <= 64 rows).  The old one-thread-per-column loop over
+// ~1000 partials ran on 3 CUs and cost 44 % of the step (profiles/r01).
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ partials, long pstride, int np, int per_group,
+                                                        float* __restrict__ out, long ostride, int ncol, float scale, int accumulate) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  const int p0 = blockIdx.y * per_group, p1 = min(np, p0 + per_group);
   float s = 0.f;
-  for (int p = 0; p < np; ++p) s += partials[(long)p * pstride + col];
-  s *= scale;
-  out[col] = accumulate ? out[col] + s : s;
+  if (col < ncol)
+    for (int p = p0 + g; p < p1; p += 8) s += partials[(long)p * pstride + col];
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && col < ncol) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    t *= scale;
+    float* o = out + (long)blockIdx.y * ostride + col;
+    *o = accumulate ? *o + t : t;
+  }
+}
+
+// scratch must hold 64 * ncol floats when np > 64
+static void launch_colreduce(const float* partials, long pstride, int np, float* out, int ncol, float scale, int accumulate,
+                             float* scratch, hipStream_t st) {
+  const int gx = (ncol + 31) / 32;
+  if (np <= 64 || scratch == nullptr) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, st, partials, pstride, np, np, out, 0L, ncol, scale, accumulate);
+    return;
+  }
+  const int per = (np + 63) / 64;
+  const int ng = (np + per - 1) / per;
+  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, ng), dim3(256), 0, st, partials, pstride, np, per, scratch, (long)ncol, ncol, 1.f, 0);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, st, scratch, (long)ncol, ng, ng, out, 0L, ncol, scale, accumulate);
 }
 
 // column sums of a bf16 [M,N] matrix (bias grads): per-(slice) partials
@@ -256,21 +284,36 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restric
 // dZ[r,:] = dl[r]*w ; dw[e] = sum_r dl[r] z[r,e] ; db = sum_r dl[r]   (M is small: B*N_e)
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ w,
                                                          bf16_t* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  float acc = 0.f, sb = 0.f;
   if (col < d) {
-    float acc = 0.f;
     const float wc = w[col];
-    for (int r = 0; r < M; ++r) {
-      const float g = dl[r];
-      acc += g * (float)Z[(long)r * d + col];
-      dZ[(long)r * d + col] = (bf16_t)(g * wc);
+    for (int r = g; r < M; r += 8) {
+      const float gr = dl[r];
+      acc += gr * (float)Z[(long)r * d + col];
+      dZ[(long)r * d + col] = (bf16_t)(gr * wc);
+      sb += gr;
     }
-    dw[col] = acc;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int r = 0; r < M; ++r) s += dl[r];
-    db[0] = s;
+  red[g][c] = acc;
+  __syncthreads();
+  if (g == 0 && col < d) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][c];
+    dw[col] = t;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    red[g][c] = (c == 0) ? sb : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 8; ++k) t += red[k][0];
+      db[0] = t;
+    }
   }
 }
 
@@ -555,7 +598,7 @@ extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamm
   return 0;
 }
 
-extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return (long)row_grid(M, 1024) * 3 * d * 4; }
+extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)row_grid(M, 1024) * 3 * d + 64L * d) * 4; }
 
 extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
                                  const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
@@ -571,11 +614,10 @@ extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, c
 #undef CALL
   HRIEMO_LAUNCH_CHECK("add_ln_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, 5.0 * M * d * 2);
-  const int g = (d + 255) / 256;
-  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace, (long)3 * d, nb, dgamma, d, 1.f, 0);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace + d, (long)3 * d, nb, dbeta, d, 1.f, 0);
-  if (dbias != nullptr)
-    hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace + 2 * d, (long)3 * d, nb, dbias, d, 1.f, 0);
+  float* scratch = workspace + (long)nb * 3 * d;
+  launch_colreduce(workspace, (long)3 * d, nb, dgamma, d, 1.f, 0, scratch, st);
+  launch_colreduce(workspace + d, (long)3 * d, nb, dbeta, d, 1.f, 0, scratch, st);
+  if (dbias != nullptr) launch_colreduce(workspace + 2 * d, (long)3 * d, nb, dbias, d, 1.f, 0, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
 }
@@ -587,7 +629,7 @@ static int colsum_slices(int M, int N) {
   if (slices < 1) slices = 1;
   return slices;
 }
-extern "C" long hriemo_colsum_workspace_bytes(int M, int N) { return (long)colsum_slices(M, N) * N * 4; }
+extern "C" long hriemo_colsum_workspace_bytes(int M, int N) { return ((long)colsum_slices(M, N) + 64) * N * 4; }
 
 extern "C" int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int accumulate, float* workspace, hipStream_t st) {
   HRIEMO_CHECK(M > 0 && N > 0 && N % 8 == 0 && ldx % 8 == 0, "colsum: bad shape M=%d N=%d ld=%ld", M, N, ldx);
@@ -596,7 +638,7 @@ extern "C" int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* 
   const int slices = colsum_slices(M, N);
   const int rps = (M + slices - 1) / slices;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ncg, slices), dim3(64), 0, st, (const bf16_t*)X, ldx, M, N, rps, workspace);
-  hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, (long)N, slices, out, N, 1.f, accumulate);
+  launch_colreduce(workspace, (long)N, slices, out, N, 1.f, accumulate, workspace + (long)slices * N, st);
   HRIEMO_LAUNCH_CHECK("colsum");
   return 0;
 }
@@ -648,7 +690,7 @@ extern "C" int hriemo_rowdot_fwd(const void* Z, const float* w, const float* b, 
 extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* w, void* dZ, float* dw, float* db, int M, int d,
                                  hipStream_t st) {
   if (check_rows(M, d)) return 1;
-  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dl, (const bf16_t*)Z, w, (bf16_t*)dZ, dw, db, M, d);
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(256), 0, st, dl, (const bf16_t*)Z, w, (bf16_t*)dZ, dw, db, M, d);
   HRIEMO_LAUNCH_CHECK("rowdot_bwd_kernel");
   return 0;
 }
@@ -726,7 +768,7 @@ extern "C" int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, cons
   return 0;
 }
 
-extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return (long)B * ((L + 31) / 32) * 2 * d * 4; }
+extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return ((long)B * ((L + 31) / 32) * 2 * d + 64L * d) * 4; }
 
 extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                                   const void* X, const float* gamma, const float* mean, const float* rstd, void* dX,
@@ -740,9 +782,9 @@ extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (2.0 * B * L + (double)B * Lf) * d * 2);
-  const int g = (d + 255) / 256;
-  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace, (long)2 * d, B * nc, dgamma, d, 1.f, 0);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(g), dim3(256), 0, st, workspace + d, (long)2 * d, B * nc, dbeta, d, 1.f, 0);
+  float* scratch = workspace + (long)B * nc * 2 * d;
+  launch_colreduce(workspace, (long)2 * d, B * nc, dgamma, d, 1.f, 0, scratch, st);
+  launch_colreduce(workspace + d, (long)2 * d, B * nc, dbeta, d, 1.f, 0, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
 }

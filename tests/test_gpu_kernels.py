@@ -201,3 +201,25 @@ def test_add_ln_fwd_bwd(ops, M, d, p, resid):
     assert (dgam.cpu() - gam.grad).abs().max() <= 2e-3 * max(1.0, gam.grad.abs().max().item())
     assert (dbet.cpu() - bet.grad).abs().max() <= 2e-3 * max(1.0, bet.grad.abs().max().item())
     assert (dbias.cpu() - Gf.grad.sum(0)).abs().max() <= 2e-2 * max(1.0, Gf.grad.sum(0).abs().max().item())
+
+
+def test_rowdot_expand(ops):
+    B, Ne, d = 5, 6, 768
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, Ne, d, generator=g).bfloat16().cuda().requires_grad_(True)
+    w = torch.nn.Parameter(torch.randn(1, d, generator=g).cuda())
+    b = torch.nn.Parameter(torch.randn(1, generator=g).cuda())
+    out = ops.RowDotFn.apply(z, w, b)
+    ref = (z.float() @ w.t()).squeeze(-1) + b
+    assert (out - ref).abs().max() <= 1e-3 * max(1.0, ref.abs().max().item())
+    dl = torch.randn(B, Ne, generator=g).cuda()
+    out.backward(dl)
+    assert (z.grad.float() - dl[..., None] * w).abs().max() <= 2e-2
+    assert (w.grad - (dl.view(-1, 1) * z.detach().float().view(-1, d)).sum(0, keepdim=True)).abs().max() <= 1e-3 * d ** 0.5
+    assert (b.grad - dl.sum()).abs().max() <= 1e-4
+    q = torch.nn.Parameter(torch.randn(Ne, d, generator=g).cuda())
+    e = ops.ExpandFn.apply(q, B)
+    assert torch.equal(e, q.detach().bfloat16()[None].expand(B, Ne, d))
+    go = torch.randn(B, Ne, d, generator=g).bfloat16().cuda()
+    e.backward(go)
+    assert (q.grad - go.float().sum(0)).abs().max() <= 1e-4
