@@ -12,6 +12,7 @@ _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 # name -> (argument codes, result): p pointer, i int, l long, f float, Q u64, I u32
 _SIGS = {
     "hriemo_gemm_bf16": ("iiiiiplplplipipliplp", "i"),
+    "hriemo_gemm_force_config": ("i", "i"),
     "hriemo_attn_fwd": ("plplplplppiiiiifQIip", "i"),
     "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQIip", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQIip", "i"),

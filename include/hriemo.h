@@ -43,6 +43,9 @@ int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long ld
                      void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
                      long ldaux, int accumulate, float* workspace, long workspace_bytes, hriemo_stream_t stream);
 
+/* tuning hook: force one of the built tile configurations (-1 = built-in heuristic) */
+int hriemo_gemm_force_config(int cfg);
+
 /* ---- attention core: softmax(QK^T/sqrt(hd) + mask) -> dropout -> .V per (batch, head), flash style.
  * Q/K/V/O/dX are read/written in place inside the projection buffers: element (b, l, h, e) of X is
  * X[(b*L + l)*ldx + h*head_dim + e].  lse [B,H,Lq] (natural log) is written by fwd, read by bwd/probs;
