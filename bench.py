@@ -128,6 +128,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         dp.step(*batch)
+    host_ms = (time.perf_counter() - t0) / a.steps * 1e3       # time to ENQUEUE a step (diagnostic)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -136,7 +137,7 @@ def main():
         dt = t.item()
     ms = dt / a.steps * 1e3
     value = B * world / (ms * 1e-3)
-    log(f"{ms:.3f} ms/step -> {value:.1f} utt/s")
+    log(f"{ms:.3f} ms/step -> {value:.1f} utt/s (host enqueue {host_ms:.3f} ms/step)")
 
     roof = None
     if rank == 0 and not a.no_roofline:
@@ -172,6 +173,7 @@ def main():
                                       "T_t=128 N_e=6 H=8, 2 fusion + 2 decoder layers, all-False masks",
                           "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}",
                           "grad_allreduce": "fp32 flat buckets 32MiB, RCCL" if world > 1 else "none"},
+               "host_enqueue_ms_per_step": round(host_ms, 3),
                "model_tflops": round(value * FLOP_PER_UTT_FWD_BWD / 1e12, 1),
                "model_mfma_frac": round(value * FLOP_PER_UTT_FWD_BWD / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
         if roof is not None:
