@@ -13,17 +13,17 @@ _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 _SIGS = {
     "hriemo_gemm_bf16": ("iiiiiplplplipipliplp", "i"),
     "hriemo_gemm_force_config": ("i", "i"),
-    "hriemo_attn_fwd": ("plplplplppiiiiifQIip", "i"),
-    "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQIip", "i"),
-    "hriemo_attn_probs": ("plplpppiiiiifQIip", "i"),
-    "hriemo_add_ln_fwd": ("pppppppiiffQIlp", "i"),
+    "hriemo_attn_fwd": ("plplplplppiiiiifQpIip", "i"),
+    "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIip", "i"),
+    "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
+    "hriemo_add_ln_fwd": ("pppppppiiffQpIlp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),
-    "hriemo_add_ln_bwd": ("pppppppppppiifQIlpp", "i"),
+    "hriemo_add_ln_bwd": ("pppppppppppiifQpIlpp", "i"),
     "hriemo_colsum_workspace_bytes": ("ii", "l"),
     "hriemo_colsum_bf16": ("pliipipp", "i"),
     "hriemo_cast_f32_to_bf16": ("pplp", "i"),
     "hriemo_cast_bf16_to_f32": ("pplp", "i"),
-    "hriemo_dropout_bf16": ("pplifQIlp", "i"),
+    "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
     "hriemo_expand_rows": ("ppilp", "i"),
     "hriemo_rowdot_fwd": ("ppppiip", "i"),
     "hriemo_rowdot_bwd": ("ppppppiip", "i"),

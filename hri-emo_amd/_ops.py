@@ -59,6 +59,24 @@ def new_site_base():
     return next(_site_counter) * 4
 
 
+_seed_words = {}
+CAPTURING = False          # set by dp.DataParallelStep.capture(): weight shadows are re-cast inside the graph
+
+
+def seed_word(device):
+    """Device-resident u64 added to every dropout seed (see include/hriemo.h): a captured step bumps it
+    in-graph so each replay draws fresh masks while kernel arguments stay frozen."""
+    t = _seed_words.get(device.index)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _seed_words[device.index] = t
+    return t
+
+
+def bump_seed_word(device):
+    seed_word(device).add_(0x9E3779B97F4A7C15 - (1 << 64))      # golden-ratio increment (mod 2^64)
+
+
 def next_seed(training):
     """Per-call dropout seed drawn from torch's CPU generator (reproducible under torch.manual_seed;
     identical on every DP rank that seeded identically)."""
@@ -78,7 +96,7 @@ class Shadows:
         key = id(p)
         ent = self._d.get(key)
         ver = (p._version, p.data_ptr())
-        if ent is None or ent[0] != ver or ent[1].device != p.device:
+        if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
             s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
                 torch.empty(p.shape, dtype=BF16, device=p.device)
             _require_gpu(p)
@@ -147,7 +165,7 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
     o = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     _lib.call("hriemo_attn_fwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-              _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, site, b_off, _stream())
+              _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _stream())
     return o, lse
 
 
@@ -155,13 +173,13 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
     delta = torch.empty_like(lse)
     _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
               _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
-              _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, site, b_off, _stream())
+              _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _stream())
 
 
 def attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off):
     out = torch.empty((B, Lq, Lk), dtype=torch.float32, device=q.device)
     _lib.call("hriemo_attn_probs", _p(q), q.stride(0), _p(k), k.stride(0), _p(kpm), _p(lse), _p(out), B, H, Lq, Lk,
-              hd, float(p), seed, site, b_off, _stream())
+              hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _stream())
     return out
 
 
@@ -171,7 +189,7 @@ def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off):
     mean = torch.empty(M, dtype=torch.float32, device=g.device)
     rstd = torch.empty(M, dtype=torch.float32, device=g.device)
     _lib.call("hriemo_add_ln_fwd", _p(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, _EPS, float(p),
-              seed, site, row_off, _stream())
+              seed, _p(seed_word(g.device)), site, row_off, _stream())
     return y, mean, rstd
 
 
@@ -183,7 +201,7 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
     stats = torch.empty((3, d), dtype=torch.float32, device=dev)
     ws = workspace(_lib.lib().hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
     _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(stats[0]),
-              _p(stats[1]), _p(stats[2]), M, d, float(p), seed, site, row_off, _p(ws), _stream())
+              _p(stats[1]), _p(stats[2]), M, d, float(p), seed, _p(seed_word(dev)), site, row_off, _p(ws), _stream())
     if dg is None:
         dg = dx           # no dropout: both branches get the same gradient
     return dx, dg, stats[0], stats[1], stats[2]
@@ -311,8 +329,8 @@ class FFNLN(torch.autograd.Function):
         hd_ = h
         if p_mid > 0:
             hd_ = torch.empty_like(h)
-            _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, site + 2, b_off * L,
-                      _stream())
+            _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
+                      site + 2, b_off * L, _stream())
         g = linear_fwd(hd_, w2_16, b2)
         y, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L)
         ctx.save_for_backward(x2, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
@@ -331,7 +349,8 @@ class FFNLN(torch.autograd.Function):
         linear_dw(dg, hd_, dw2)
         da = linear_dx(dg, w2_16, epi=2, aux=h)          # * relu'(h)
         if p_mid > 0:
-            _lib.call("hriemo_dropout_bf16", _p(da), _p(da), M, F, float(p_mid), seed, site + 2, b_off * L, _stream())
+            _lib.call("hriemo_dropout_bf16", _p(da), _p(da), M, F, float(p_mid), seed, _p(seed_word(dev)), site + 2, b_off * L,
+                      _stream())
         dw1 = torch.empty((F, d), dtype=torch.float32, device=dev)
         linear_dw(da, x2, dw1)
         db1 = torch.empty(F, dtype=torch.float32, device=dev)

@@ -32,6 +32,7 @@ struct AttnArgs {
   int B, H, Lq, Lk;
   float scale;
   uint32_t thr16; float inv_keep; uint64_t seed; uint32_t site; int b_offset;
+  const unsigned long long* seed_dev;
 };
 
 #define LOG2E 1.4426950408889634f
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
     for (int dt = 0; dt < DT; ++dt) o[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const float sl2 = a.scale * LOG2E;
-  const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
   const bf16_t* Kb = a.K + (long)b * a.Lk * a.ldk + h * HD;
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
   const int nkt = (a.Lk + 63) >> 6;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
     for (int dt = 0; dt < DT; ++dt) dq[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float sl2 = a.scale * LOG2E;
-  const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
   const bf16_t* Kb = a.K + (long)b * a.Lk * a.ldk + h * HD;
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
   const int nkt = (a.Lk + 63) >> 6;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
       dv[kw][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   const float sl2 = a.scale * LOG2E;
-  const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
   const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
   const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
   const long lbase = ((long)b * a.H + h) * a.Lq;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a) {
         }
       }
     }
-    const uint32_t key32 = site_key(a.seed, a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+    const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int q = min(q0 + r, a.Lq - 1);
@@ -559,21 +560,21 @@ static int check_common(const AttnArgs& a, int hd) {
     case 128: { CALL(128); } break;         \
   }
 
-static void fill_drop(AttnArgs& a, float p, uint64_t seed, uint32_t site, int b_offset) {
+static void fill_drop(AttnArgs& a, float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, int b_offset) {
   DropCfg d = make_drop(p, seed, site);
-  a.thr16 = d.thr16; a.inv_keep = d.inv_keep; a.seed = seed; a.site = site; a.b_offset = b_offset;
+  a.thr16 = d.thr16; a.inv_keep = d.inv_keep; a.seed = seed; a.site = site; a.b_offset = b_offset; a.seed_dev = seed_dev;
 }
 
 extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                                long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
-                               int Lk, int head_dim, float p_drop, unsigned long long seed, unsigned site,
-                               int b_offset, hipStream_t st) {
+                               int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                               unsigned site, int b_offset, hipStream_t st) {
   AttnArgs a = {};
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
   a.kpm = key_padding_mask; a.lse = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
-  fill_drop(a, p_drop, seed, site, b_offset);
+  fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
   if (check_common(a, head_dim)) return 1;
   HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: unaligned O");
   hriemo_prof_begin(HP_ATTN_FWD, st);
@@ -599,7 +600,8 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
                                const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
                                long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
                                const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
-                               float p_drop, unsigned long long seed, unsigned site, int b_offset, hipStream_t st) {
+                               float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                               hipStream_t st) {
   AttnArgs a = {};
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
@@ -607,7 +609,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.kpm = key_padding_mask; a.lse = (float*)lse; a.delta = delta; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
-  fill_drop(a, p_drop, seed, site, b_offset);
+  fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
   if (check_common(a, head_dim)) return 1;
   HRIEMO_CHECK(ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: bad leading dims");
   HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
@@ -649,13 +651,14 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
 
 extern "C" int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,
                                  const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim,
-                                 float p_drop, unsigned long long seed, unsigned site, int b_offset, hipStream_t st) {
+                                 float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                               hipStream_t st) {
   AttnArgs a = {};
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)K;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldk;
   a.kpm = key_padding_mask; a.lse = (float*)lse; a.probs = probs; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
-  fill_drop(a, p_drop, seed, site, b_offset);
+  fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
   if (check_common(a, head_dim)) return 1;
 #define CALL(HD) hipLaunchKernelGGL((attn_probs_kernel<HD>), dim3((Lk + 63) / 64, (Lq + 7) / 8, B), dim3(64), 0, st, a)
   DISPATCH_HD(head_dim, CALL)

@@ -68,6 +68,11 @@ struct DropCfg {
   uint32_t thr16;     // 0 => dropout off
   float inv_keep;     // 1 / (1 - thr16/65536)
 };
+// Effective seed = immediate seed + *seed_dev (device word, may be NULL).  The device word lets a captured
+// hipGraph draw fresh masks on every replay: the graph itself bumps it, the kernel arguments stay frozen.
+__device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const unsigned long long* seed_dev) {
+  return seed + (seed_dev != nullptr ? (uint64_t)*seed_dev : 0ull);
+}
 static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
   DropCfg d;
   d.seed = seed; d.site = site;

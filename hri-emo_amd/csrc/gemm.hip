@@ -104,7 +104,7 @@ __device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, c
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS>
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int STAG>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
   constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -153,6 +153,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  auto load_frags = [&](const char* sa, int ks, bf16x8 (&af)[MT], bf16x8 (&bfr)[NTL]) {
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+      af[mi] = TA == 0 ? lds_row_frag(sa, wm * MT * 16 + mi * 16, ks, lane) : lds_tr_frag<BM * 2>(sa, wm * MT * 16 + mi * 16, ks, lane);
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni)
+      bfr[ni] = TB == 0 ? lds_row_frag(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
+  };
+  auto mma_rows = [&](const bf16x8 (&af)[MT], const bf16x8 (&bfr)[NTL], int lo, int hi) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+      if (mi >= lo && mi < hi) {
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bfr)[NTL]) { mma_rows(af, bfr, 0, MT); };
+
   // prologue: put NS-1 stages in flight, retire the first
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
@@ -160,33 +182,76 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
   if (nk > NS - 2) wait_vmcnt<(NS - 2) * LPT>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
   int cur = 0, nxt = NS - 1;          // ring slots of the stage being computed / being filled
-  for (int it = 0; it < nk; ++it) {
-    if (it + NS - 1 < nk) stage(nxt, it + NS - 1);
-    const char* sa = smem + cur * STAGE;
-    const char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[MT], bfr[NTL];
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
-        af[mi] = TA == 0 ? lds_row_frag(sa, wm * MT * 16 + mi * 16, ks, lane) : lds_tr_frag<BM * 2>(sa, wm * MT * 16 + mi * 16, ks, lane);
-#pragma unroll
-      for (int ni = 0; ni < NTL; ++ni)
-        bfr[ni] = TB == 0 ? lds_row_frag(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NTL; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+  if (STAG) {
+    // Staggered two-group schedule.  A SIMD hosts wave w (group 0) and wave w + NWAVE/2 (group 1).  Every
+    // K-step is split into an S-phase (LDS-DMA issue for stage it+NS-1, all fragment reads of stage it) and
+    // an M-phase (MFMAs only), each closed by a barrier; group 1 runs one phase behind, so on every SIMD one
+    // wave feeds the matrix pipe while its partner pays the DMA-issue / LDS-read time.  Needs NS >= 3:
+    // stage it is read at slots 2it (g0) / 2it+1 (g1); every wave confirms its share of stage it at the end
+    // of S(it-1) (counted vmcnt, then barrier), and the slot is only restaged in S(it+1), one barrier after
+    // the last group-1 read was retired (lgkmcnt(0) before the barrier).
+    static_assert(!STAG || NS >= 3, "stagger needs a 3-deep ring");
+    const bool g1 = wave >= NWAVE / 2;
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < nk; ++it) {
+      if (it + NS - 1 < nk) stage(nxt, it + NS - 1);
+      load_frags(smem + cur * STAGE, 0, afA, bfA);
+      load_frags(smem + cur * STAGE, 1, afB, bfB);
+      if (it + NS - 1 < nk) wait_vmcnt<(NS - 2) * LPT>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mma(afA, bfA);
+      mma(afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
-    // stage it+1 must have landed for every wave before anyone reads it; stages it+2.. stay in flight
-    if (it + NS - 1 < nk) wait_vmcnt<(NS - 2) * LPT>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    cur = (cur + 1 == NS) ? 0 : cur + 1;
-    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    if (!g1) __builtin_amdgcn_s_barrier();
+  } else {
+    // Software pipeline across the barrier: while the MFMAs of one 32-deep half-step run, the fragments of
+    // the next half-step are already being read (two register sets), and the retire-wait + barrier for
+    // stage it+1 sits in the MIDDLE of iteration it, so its first fragments load under the second cluster.
+    // Order inside an iteration (pinned with sched_barrier(0): hipcc otherwise moves the register-only MFMA
+    // clusters across the waits and the barrier, rule 18):
+    //   DMA(it+NS-1) | MFMA(A, rows 0..MT/2) | read B-set | MFMA(A, rest) | retire stage it+1 + barrier |
+    //   read next A-set | MFMA(B-set)
+    // so every fragment read has >= half a cluster of MFMAs to land, and the LDS-read retire before the
+    // barrier is a builtin s_waitcnt (lgkmcnt(0) only) the compiler can see, so it adds no wait of its own
+    // in front of the B cluster.
+    if (nk > 0) load_frags(smem, 0, afA, bfA);
+    for (int it = 0; it < nk; ++it) {
+      if (it + NS - 1 < nk) stage(nxt, it + NS - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_rows(afA, bfA, 0, MT / 2);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(smem + cur * STAGE, 1, afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_rows(afA, bfA, MT / 2, MT);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      if (it + 1 < nk) {
+        // stage it+1 must have landed for every wave; our own reads of stage `it` must be retired before any
+        // wave may restage that slot (WAR).
+        if (it + NS - 1 < nk) wait_vmcnt<(NS - 2) * LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone
+        __builtin_amdgcn_s_barrier();
+        load_frags(smem + cur * STAGE, 0, afA, bfA);
+      } else {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(afB, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  __syncthreads();                    // everyone is done with the ring before it becomes the C staging area
 
   // ---- epilogue.  A lane owns C[m = .. + (lane&15)][n = .. + 4*(lane>>4) .. +3] of each 16x16 tile.
   const int g = lane >> 4, i = lane & 15;
@@ -225,11 +290,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
           if (p.epi == 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (p.epi >= 2) {
+          } else if (p.epi == 3) {
             const bf16x4 a4 = *(const bf16x4*)(p.aux + (long)m * p.ldaux + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = p.epi == 2 ? (((float)a4[e] > 0.f) ? v[e] : 0.f) : v[e] + (float)a4[e];
-          }
+            for (int e = 0; e < 4; ++e) v[e] += (float)a4[e];
+          }   // epi == 2 (ReLU mask) commutes with the bf16 rounding: applied below on full 16-B lines
         }
         bf16x4 o;
 #pragma unroll
@@ -245,7 +310,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
       const int r = id / CPR, cc = id % CPR;
       const int m = m0 + r, n = n0 + cc * 8;
       if (m < p.M && n < p.N) {
-        const bf16x8 v = *(LDS_PTR(const bf16x8))(smem + r * (BN * 2) + ((cc ^ (r & 15)) << 4));
+        bf16x8 v = *(LDS_PTR(const bf16x8))(smem + r * (BN * 2) + ((cc ^ (r & 15)) << 4));
+        if (p.epi == 2) {
+          const bf16x8 a8 = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ((float)a8[e] > 0.f) ? v[e] : (bf16_t)0.f;
+        }
         *(bf16x8*)((bf16_t*)p.C + (long)m * p.ldc + n) = v;
       }
     }
@@ -276,6 +346,8 @@ static const TileCfg kCfg[] = {
     {256, 256, 512, 2 * 65536},   // 3: 256x256, 2x4 waves (128x64 per wave), 2 stages
     {256, 128, 512, 2 * 49152},   // 4: 256x128, 4x2 waves, 2 stages
     {128, 256, 512, 3 * 49152},   // 5: 128x256, 2x4 waves, 3 stages
+    {256, 128, 512, 3 * 49152},   // 6: 256x128, 4x2 waves, 3 stages, staggered S/M phases
+    {128, 256, 512, 3 * 49152},   // 7: 128x256, 2x4 waves, 3 stages, staggered S/M phases
 };
 static const int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 static int g_force_cfg = -1;
@@ -284,15 +356,15 @@ extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev
   return 0;
 }
 
-template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS>
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int STAG = 0>
 static void launch_one(const GemmArgs& a, int lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int grid = a.tiles_m * a.tiles_n * a.splitk;
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, STAG>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
 }
 
 template <int TA, int TB, int OUTF32>
@@ -304,7 +376,9 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     case 2: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3>(a, lds, st); break;
     case 3: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 2>(a, lds, st); break;
     case 4: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 2>(a, lds, st); break;
-    default: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3>(a, lds, st); break;
+    case 5: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3>(a, lds, st); break;
+    case 6: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3, 1>(a, lds, st); break;
+    default: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3, 1>(a, lds, st); break;
   }
 }
 
@@ -313,11 +387,10 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
 // narrow outputs (N = d_model) keep the 128x128 tile at 2 blocks/CU.
 static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
-  (void)tb;
   if (ta == 1) return (M >= 512 && N >= 512 && (long)K >= 4096) ? 3 : 0;     // dW: split-K fills the chip
-  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  if (N >= 2048 && tiles256 >= 512) return 3;
-  return 0;
+  if (M < 1024 || N < 256) return 0;                                          // decoder / gate sized problems
+  if (tb == 0) return (N >= 2048 && M >= 16384) ? 3 : 7;                      // NT: 256x256, else staggered 128x256
+  return M >= 16384 ? 3 : 4;                                                  // NN
 }
 
 extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
@@ -332,7 +405,7 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   if (ta == 0) HRIEMO_CHECK(K % 8 == 0, "gemm: K=%d must be a multiple of 8 for a K-contiguous operand", K);
   if (ta == 1) HRIEMO_CHECK(M % 8 == 0, "gemm: M=%d must be a multiple of 8 for a transposed A", M);
   HRIEMO_CHECK(c_is_f32 || (epilogue >= 0 && epilogue <= 3), "gemm: bad epilogue");
-  HRIEMO_CHECK(epilogue < 2 || (aux != nullptr && ldaux % 4 == 0), "gemm: epilogue 2/3 needs aux");
+  HRIEMO_CHECK(epilogue < 2 || (aux != nullptr && ldaux % 8 == 0 && ((uintptr_t)aux % 16) == 0), "gemm: epilogue 2/3 needs a 16-byte aligned aux");
   HRIEMO_CHECK(!(c_is_f32 && epilogue != 0), "gemm: fp32 output has no activation epilogue");
   HRIEMO_CHECK(c_is_f32 || !accumulate, "gemm: accumulate needs fp32 output");
 

@@ -10,11 +10,14 @@
 
 #define EPS_DEFAULT 1e-5f
 
-struct RowDrop { uint32_t key32, thr16; float inv_keep; };
-static RowDrop row_drop(float p, uint64_t seed, uint32_t site) {
+struct RowDrop { uint64_t seed; const unsigned long long* seed_dev; uint32_t site, thr16; float inv_keep; };
+static RowDrop row_drop(float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site) {
   DropCfg d = make_drop(p, seed, site);
-  RowDrop r; r.key32 = site_key(seed, site, 0u); r.thr16 = d.thr16; r.inv_keep = d.inv_keep;
+  RowDrop r; r.seed = seed; r.seed_dev = seed_dev; r.site = site; r.thr16 = d.thr16; r.inv_keep = d.inv_keep;
   return r;
+}
+__device__ __forceinline__ uint32_t row_key(const RowDrop& dr) {
+  return dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, 0u) : 0u;
 }
 
 // deterministic accumulate of per-wave column partials into an LDS row, wave by wave
@@ -45,6 +48,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ Y, float* __restrict__ mean_o,
                                                          float* __restrict__ rstd_o, int M, int d, float eps, RowDrop dr,
                                                          long row_offset) {
+  const uint32_t key32 = row_key(dr);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
   const float invd = 1.f / (float)d;
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float gv = gf[j];
-          if (dr.thr16 != 0) gv = keep16(dr.key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? gv * dr.inv_keep : 0.f;
+          if (dr.thr16 != 0) gv = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? gv * dr.inv_keep : 0.f;
           s[c][j] = (X != nullptr ? xf[j] : 0.f) + gv;
           sum += s[c][j];
         }
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
                                                          bf16_t* __restrict__ dX, bf16_t* __restrict__ dG,
                                                          float* __restrict__ partials, int M, int d, RowDrop dr,
                                                          long row_offset) {
+  const uint32_t key32 = row_key(dr);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;   // [3][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
           float gv = gf[j];
           kp[c][j] = true;
           if (dr.thr16 != 0) {
-            kp[c][j] = keep16(dr.key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16);
+            kp[c][j] = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16);
             gv = kp[c][j] ? gv * dr.inv_keep : 0.f;
           }
           const float sv = (X != nullptr ? xf[j] : 0.f) + gv;
@@ -245,6 +250,7 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __re
 }
 
 __global__ void dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ Y, long M, int N, RowDrop dr, long row_offset) {
+  const uint32_t key32 = row_key(dr);
   const int nch = N >> 3;
   const long nv = M * nch;
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
@@ -254,7 +260,7 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict_
     bf8_to_f32(*(const bf16x8*)(X + v * 8), f);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      f[j] = keep16(dr.key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? f[j] * dr.inv_keep : 0.f;
+      f[j] = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? f[j] * dr.inv_keep : 0.f;
     *(bf16x8*)(Y + v * 8) = f32_to_bf8(f);
   }
 }
@@ -585,10 +591,10 @@ static int check_rows(int M, int d) {
 static int row_grid(int M, int cap) { int g = (M + 3) / 4; return g > cap ? cap : g; }
 
 extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
-                                 float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed, unsigned site,
-                                 long row_offset, hipStream_t st) {
+                                 float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                                 const unsigned long long* seed_dev, unsigned site, long row_offset, hipStream_t st) {
   if (check_rows(M, d)) return 1;
-  RowDrop dr = row_drop(p_drop, seed, site);
+  RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
   hriemo_prof_begin(HP_ROWOPS, st);
 #define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, gamma, beta, (bf16_t*)Y, mean, rstd, M, d, eps, dr, row_offset)
   DISPATCH_NCH(d, CALL)
@@ -602,11 +608,11 @@ extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)
 
 extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
                                  const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
-                                 float p_drop, unsigned long long seed, unsigned site, long row_offset, float* workspace,
-                                 hipStream_t st) {
+                                 float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
+                                 long row_offset, float* workspace, hipStream_t st) {
   if (check_rows(M, d)) return 1;
   HRIEMO_CHECK(workspace != nullptr, "add_ln_bwd: workspace required");
-  RowDrop dr = row_drop(p_drop, seed, site);
+  RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
   const int nb = row_grid(M, 1024);
   hriemo_prof_begin(HP_ROWOPS, st);
 #define CALL(N) hipLaunchKernelGGL((add_ln_bwd_kernel<N>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, (const bf16_t*)X, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
@@ -661,10 +667,10 @@ extern "C" int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hipS
   return 0;
 }
 
-extern "C" int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed, unsigned site,
-                                   long row_offset, hipStream_t st) {
+extern "C" int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed,
+                                   const unsigned long long* seed_dev, unsigned site, long row_offset, hipStream_t st) {
   HRIEMO_CHECK(M > 0 && N > 0 && N % 8 == 0, "dropout: bad shape");
-  RowDrop dr = row_drop(p_drop, seed, site);
+  RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
   long g = (M * (N / 8) + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3((int)g), dim3(256), 0, st, (const bf16_t*)X, (bf16_t*)Y, M, N, dr, row_offset);

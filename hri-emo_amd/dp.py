@@ -97,13 +97,22 @@ def shard_bounds(global_batch, rank, world):
 
 class DataParallelStep:
     """fwd -> loss -> bwd -> gradient all-reduce for one shard; mirrors the order of operations of
-    train_one_epoch (scripts/fusion/train_fusion_seq_level_decoder.py:310-334) minus the optimizer."""
+    train_one_epoch (scripts/fusion/train_fusion_seq_level_decoder.py:310-334) minus the optimizer.
+
+    ``capture()`` records zero-grad + forward + loss + backward of one step into a hipGraph (the eager step
+    costs ~10 ms of host time for ~150 launches; a replay costs microseconds).  Dropout stays fresh per
+    replay through the device-resident seed word the graph bumps itself (``_ops.seed_word``); bf16 weight
+    shadows are re-cast inside the graph so optimizer updates between replays are honoured.  The gradient
+    all-reduce runs after the replay on the flat buffer."""
 
     def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True):
         self.model, self.loss_fn = model, loss_fn
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap)
+        self._graph = None
+        self._static = None
+        self._static_loss = None
 
     def set_global_batch(self, global_batch):
         lo, hi = shard_bounds(global_batch, self.rank, self.world)
@@ -111,10 +120,44 @@ class DataParallelStep:
             self.model.set_batch_offset(lo)
         return lo, hi
 
-    def step(self, h_a, h_t, m_a, m_t, y):
+    def _fwd_bwd(self, h_a, h_t, m_a, m_t, y):
         self.buckets.zero_grad()
         logits, beta, _ = self.model(h_a, h_t, m_a, m_t)
         loss = self.loss_fn(logits, beta, y)
         loss.backward()
-        self.buckets.finish()
         return loss.detach()
+
+    def capture(self, h_a, h_t, m_a, m_t, y):
+        """Record one step on static copies of the batch tensors; later ``step()`` calls replay it."""
+        from . import _ops
+        if self.buckets._hooks:
+            raise RuntimeError("capture() needs GradBuckets(overlap=False): collectives are not captured")
+        self._static = [None if t is None else t.clone() for t in (h_a, h_t, m_a, m_t, y)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture wants
+            for _ in range(2):
+                self._fwd_bwd(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        _ops.CAPTURING = True
+        try:
+            with torch.cuda.graph(graph):
+                _ops.bump_seed_word(self._static[0].device)
+                self._static_loss = self._fwd_bwd(*self._static)
+        finally:
+            _ops.CAPTURING = False
+        self._graph = graph
+
+    def step(self, h_a, h_t, m_a, m_t, y):
+        if self._graph is not None:
+            for s, t in zip(self._static, (h_a, h_t, m_a, m_t, y)):
+                if s is not None and t is not None and s.data_ptr() != t.data_ptr():
+                    s.copy_(t)
+            self._graph.replay()
+            self.buckets.finish()
+            return self._static_loss
+        loss = self._fwd_bwd(h_a, h_t, m_a, m_t, y)
+        self.buckets.finish()
+        return loss

@@ -13,7 +13,8 @@
  *    statistics, parameters' masters, gradients of parameters are fp32;
  *  - masks are uint8 [B, L], 1 = PAD (the reference's key_padding_mask convention);
  *  - dropout is replayed from (seed, site, row/col) -- the backward takes the same triple, no mask is
- *    stored; p_drop = 0 disables it;  b_offset / row_offset = global index of the first utterance/row
+ *    stored; p_drop = 0 disables it; the effective seed is seed + *seed_dev (device word, may be NULL) so a
+ *    captured hipGraph can draw fresh masks per replay by bumping that word inside the graph;  b_offset / row_offset = global index of the first utterance/row
  *    of this shard so masks do not depend on how the batch is sharded over GPUs;
  *  - `stream` is a hipStream_t; return 0 = ok, otherwise hriemo_last_error() explains.
  */
@@ -53,30 +54,32 @@ int hriemo_gemm_force_config(int cfg);
  * projections (cross_modal_block_tacfn.py:74-80,85-91,98-104,111-117; emotion_decoder.py:42,48-54). */
 int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
                     const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
-                    float p_drop, unsigned long long seed, unsigned site, int b_offset, hriemo_stream_t stream);
+                    float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                    hriemo_stream_t stream);
 int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O, long ldo,
                     const void* dO, long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
                     const unsigned char* key_padding_mask, const float* lse, float* delta, int B, int H, int Lq,
-                    int Lk, int head_dim, float p_drop, unsigned long long seed, unsigned site, int b_offset,
-                    hriemo_stream_t stream);
+                    int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                    unsigned site, int b_offset, hriemo_stream_t stream);
 /* head-averaged attention probabilities [B,Lq,Lk] fp32 (need_weights=True; return_attention path,
  * cross_modal_block_tacfn.py:70-125, emotion_decoder.py:48-64) */
 int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,
                       const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, float p_drop,
-                      unsigned long long seed, unsigned site, int b_offset, hriemo_stream_t stream);
+                      unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                      hriemo_stream_t stream);
 
 /* ---- y = LayerNorm(x + dropout(g)), eps, affine (X may be NULL: plain LayerNorm of g).
  * Replaces norm(h + self.dropout(sub(h))) (cross_modal_block_tacfn.py:81,92,105,106,118,119;
  * emotion_decoder.py:43,55,59).  bwd writes dX (residual branch), dG (sub-layer branch, dropout mask
  * applied) and the column sums dgamma, dbeta, dbias (= colsum dG, the producing Linear's bias grad). */
 int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
-                      float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed, unsigned site,
-                      long row_offset, hriemo_stream_t stream);
+                      float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                      const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);
 long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
 int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
                       const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
-                      float p_drop, unsigned long long seed, unsigned site, long row_offset, float* workspace,
-                      hriemo_stream_t stream);
+                      float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
+                      long row_offset, float* workspace, hriemo_stream_t stream);
 
 /* ---- small glue on the path */
 long hriemo_colsum_workspace_bytes(int M, int N);
@@ -84,8 +87,8 @@ int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int ac
                        hriemo_stream_t stream);                                   /* bias gradients */
 int hriemo_cast_f32_to_bf16(const float* src, void* dst, long n, hriemo_stream_t stream);   /* bf16 shadows */
 int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hriemo_stream_t stream);
-int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed, unsigned site,
-                        long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
+int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed,
+                        const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
 int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
 int hriemo_rowdot_fwd(const void* Z, const float* w, const float* b, float* out, int M, int d,
                       hriemo_stream_t stream);                                     /* emotion_decoder.py:155 */
