@@ -23,7 +23,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 CFG = dict(d_model=768, num_emotions=6, n_heads=8, num_layers_fusion=2, num_layers_decoder=2, beta_hidden=256,
-           dropout=0.1)
+           dropout=float(os.environ.get("HRIEMO_BENCH_DROPOUT", "0.1")))     # 0.1 = reference default (the headline)
 T_A, T_T = 400, 128
 FLOP_PER_UTT_FWD_BWD = 65.378e9           # SURVEY.md 8(d), closed form == FlopCounterMode
 PEAK_BF16_TFLOPS = 2500.0                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)

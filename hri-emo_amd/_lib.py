@@ -18,7 +18,7 @@ _SIGS = {
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppiiffQpIlp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),
-    "hriemo_add_ln_bwd": ("pppppppppppiifQpIlpp", "i"),
+    "hriemo_add_ln_bwd": ("pppppppppppiiifQpIlpp", "i"),
     "hriemo_colsum_workspace_bytes": ("ii", "l"),
     "hriemo_colsum_bf16": ("pliipipp", "i"),
     "hriemo_cast_f32_to_bf16": ("pplp", "i"),

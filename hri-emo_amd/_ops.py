@@ -109,6 +109,35 @@ class Shadows:
         return ent[1]
 
 
+FUSED_WGRAD = True
+
+
+class GradSink:
+    """Where a Function's parameter gradients go.  If every parameter already owns a dense fp32 ``.grad``
+    (zero_grad(set_to_none=False), or the flat-buffer views of dp.GradBuckets) the kernels accumulate
+    straight into it (GEMM / column-reduce ``accumulate`` flag) and the Function returns None for it:
+    no temporary, no autograd add kernel.  Otherwise fresh tensors are returned to autograd as usual."""
+
+    def __init__(self, params):
+        self.params = params
+        self.fused = FUSED_WGRAD and all(
+            p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+            and p.grad.device == p.device and p.grad.shape == p.shape for p in params)
+
+    def buf(self, p):
+        return p.grad if self.fused else torch.empty(p.shape, dtype=torch.float32, device=p.device)
+
+    def ret(self, t):
+        return None if self.fused else t
+
+    def done(self):
+        if self.fused:
+            for p in self.params:
+                hook = getattr(p, "_hriemo_grad_ready", None)
+                if hook is not None:
+                    hook(p)
+
+
 def to_bf16(x):
     return x if x.dtype == BF16 else x.to(BF16)
 
@@ -148,17 +177,17 @@ def linear_dx(dy, w16, epi=0, aux=None):
     return dx
 
 
-def linear_dw(dy, x, out):
-    """out[N,K] (fp32, row stride free) = dY[M,N]^T . X[M,K]"""
+def linear_dw(dy, x, out, accumulate=False):
+    """out[N,K] (fp32, row stride free) (+)= dY[M,N]^T . X[M,K]"""
     M, N = dy.shape
     K = x.shape[1]
-    gemm(1, 1, N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True)
+    gemm(1, 1, N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True, accumulate=accumulate)
 
 
-def colsum(x, out):
+def colsum(x, out, accumulate=False):
     M, N = x.shape
     ws = workspace(_lib.lib().hriemo_colsum_workspace_bytes(M, N), x.device, slot=1)
-    _lib.call("hriemo_colsum_bf16", _p(x), x.stride(0), M, N, _p(out), 0, _p(ws), _stream())
+    _lib.call("hriemo_colsum_bf16", _p(x), x.stride(0), M, N, _p(out), int(accumulate), _p(ws), _stream())
 
 
 def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
@@ -193,18 +222,22 @@ def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off):
     return y, mean, rstd
 
 
-def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True):
+def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True, outs=None, accumulate=False):
+    """outs = (dgamma, dbeta, dbias) destination tensors (fp32 [d]); fresh ones when None."""
     M, d = g.shape
     dev = g.device
     dx = torch.empty((M, d), dtype=BF16, device=dev) if want_dx else None
     dg = torch.empty((M, d), dtype=BF16, device=dev) if (p > 0 or not want_dx) else None
-    stats = torch.empty((3, d), dtype=torch.float32, device=dev)
+    if outs is None:
+        stats = torch.empty((3, d), dtype=torch.float32, device=dev)
+        outs = (stats[0], stats[1], stats[2])
     ws = workspace(_lib.lib().hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
-    _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(stats[0]),
-              _p(stats[1]), _p(stats[2]), M, d, float(p), seed, _p(seed_word(dev)), site, row_off, _p(ws), _stream())
+    _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
+              _p(outs[1]), _p(outs[2]), int(accumulate), M, d, float(p), seed, _p(seed_word(dev)), site, row_off,
+              _p(ws), _stream())
     if dg is None:
         dg = dx           # no dropout: both branches get the same gradient
-    return dx, dg, stats[0], stats[1], stats[2]
+    return dx, dg, outs[0], outs[1], outs[2]
 
 
 def _heads(d, H):
@@ -241,6 +274,7 @@ class SelfAttnLN(torch.autograd.Function):
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(x2, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
+        ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
         return y.view(B, L, d), probs
 
@@ -251,19 +285,26 @@ class SelfAttnLN(torch.autograd.Function):
         M = B * L
         dev = x2.device
         dy2 = _contig_bf16(dy).view(M, d)
-        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L)
-        dw_out = torch.empty((d, d), dtype=torch.float32, device=dev)
-        linear_dw(dg, o, dw_out)
+        p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
+        sink = GradSink(ctx.params)
+        acc = sink.fused
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L,
+                                                   outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
+                                                   accumulate=acc)
+        dw_out = sink.buf(p_w_out)
+        linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
         dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
         attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
                  lse, B, H, L, L, hd, kpm, p, seed, site, b_off)
-        dw_in = torch.empty((3 * d, d), dtype=torch.float32, device=dev)
-        linear_dw(dqkv, x2, dw_in)
-        db_in = torch.empty(3 * d, dtype=torch.float32, device=dev)
-        colsum(dqkv, db_in)
+        dw_in = sink.buf(p_w_in)
+        linear_dw(dqkv, x2, dw_in, acc)
+        db_in = sink.buf(p_b_in)
+        colsum(dqkv, db_in, acc)
         dx = linear_dx(dqkv, w_in16, epi=3, aux=ds)
-        return (dx.view(B, L, d), dw_in, db_in, dw_out, db_out, dgamma, dbeta) + (None,) * 8
+        sink.done()
+        r = sink.ret
+        return (dx.view(B, L, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8
 
 
 class CrossAttnLN(torch.autograd.Function):
@@ -287,6 +328,7 @@ class CrossAttnLN(torch.autograd.Function):
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(xq2, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
+        ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
         return y.view(B, Lq, d), probs
 
@@ -296,23 +338,31 @@ class CrossAttnLN(torch.autograd.Function):
         B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
         dev = xq2.device
         dy2 = _contig_bf16(dy).view(B * Lq, d)
-        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * Lq)
-        dw_out = torch.empty((d, d), dtype=torch.float32, device=dev)
-        linear_dw(dg, o, dw_out)
+        p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
+        sink = GradSink(ctx.params)
+        acc = sink.fused
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * Lq,
+                                                   outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
+                                                   accumulate=acc)
+        dw_out = sink.buf(p_w_out)
+        linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
         dq = torch.empty((B * Lq, d), dtype=BF16, device=dev)
         dkv = torch.empty((B * Lk, 2 * d), dtype=BF16, device=dev)
         attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm, p, seed,
                  site, b_off)
-        dw_in = torch.empty((3 * d, d), dtype=torch.float32, device=dev)
-        linear_dw(dq, xq2, dw_in[:d])
-        linear_dw(dkv, xkv2, dw_in[d:])
-        db_in = torch.empty(3 * d, dtype=torch.float32, device=dev)
-        colsum(dq, db_in[:d])
-        colsum(dkv, db_in[d:])
+        dw_in = sink.buf(p_w_in)
+        linear_dw(dq, xq2, dw_in[:d], acc)
+        linear_dw(dkv, xkv2, dw_in[d:], acc)
+        db_in = sink.buf(p_b_in)
+        colsum(dq, db_in[:d], acc)
+        colsum(dkv, db_in[d:], acc)
         dxq = linear_dx(dq, w_in16[:d], epi=3, aux=ds)
         dxkv = linear_dx(dkv, w_in16[d:])
-        return (dxq.view(B, Lq, d), dxkv.view(B, Lk, d), dw_in, db_in, dw_out, db_out, dgamma, dbeta) + (None,) * 8
+        sink.done()
+        r = sink.ret
+        return (dxq.view(B, Lq, d), dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
+                r(dbeta)) + (None,) * 8
 
 
 class FFNLN(torch.autograd.Function):
@@ -335,6 +385,7 @@ class FFNLN(torch.autograd.Function):
         y, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L)
         ctx.save_for_backward(x2, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
         ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)
+        ctx.params = (w1, b1, w2, b2, gamma, beta)
         return y.view(B, L, d)
 
     @staticmethod
@@ -344,19 +395,26 @@ class FFNLN(torch.autograd.Function):
         M, F = h.shape
         dev = x2.device
         dy2 = _contig_bf16(dy).view(M, d)
-        ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L)
-        dw2 = torch.empty((d, F), dtype=torch.float32, device=dev)
-        linear_dw(dg, hd_, dw2)
+        p_w1, p_b1, p_w2, p_b2, p_gamma, p_beta = ctx.params
+        sink = GradSink(ctx.params)
+        acc = sink.fused
+        ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L,
+                                                outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b2)),
+                                                accumulate=acc)
+        dw2 = sink.buf(p_w2)
+        linear_dw(dg, hd_, dw2, acc)
         da = linear_dx(dg, w2_16, epi=2, aux=h)          # * relu'(h)
         if p_mid > 0:
             _lib.call("hriemo_dropout_bf16", _p(da), _p(da), M, F, float(p_mid), seed, _p(seed_word(dev)), site + 2, b_off * L,
                       _stream())
-        dw1 = torch.empty((F, d), dtype=torch.float32, device=dev)
-        linear_dw(da, x2, dw1)
-        db1 = torch.empty(F, dtype=torch.float32, device=dev)
-        colsum(da, db1)
+        dw1 = sink.buf(p_w1)
+        linear_dw(da, x2, dw1, acc)
+        db1 = sink.buf(p_b1)
+        colsum(da, db1, acc)
         dx = linear_dx(da, w1_16, epi=3, aux=ds)
-        return (dx.view(B, L, d), dw1, db1, dw2, db2, dgamma, dbeta) + (None,) * 6
+        sink.done()
+        r = sink.ret
+        return (dx.view(B, L, d), r(dw1), r(db1), r(dw2), r(db2), r(dgamma), r(dbeta)) + (None,) * 6
 
 
 class BetaGateFn(torch.autograd.Function):

@@ -174,43 +174,48 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
   for (int t = threadIdx.x; t < 3 * d; t += 256) out[t] = red[t];
 }
 
-// out[g][col] (+)= scale * sum_{p in group g} partials[p][col]  -- fixed order, two-level tree:
-// block = 32 columns x 8 row-lanes; blockIdx.y = group of `per_group` partials (pass 1 writes one row
-// per group into a scratch, pass 2 folds those <= 64 rows).  The old one-thread-per-column loop over
-// ~1000 partials ran on 3 CUs and cost 44 % of the step (profiles/r01).
+// Column reduce of per-block partials, fixed order, two-level tree.  partials: [np][nseg*w] fp32.
+// block = 32 columns x 8 row-lanes; blockIdx.y = group of `per_group` partial rows.  Pass 1 (np > 64) folds
+// groups into a scratch [ng][nseg*w]; the final pass writes segment z of the columns to its own output
+// pointer (dgamma / dbeta / dbias live in different .grad buffers), optionally accumulating.
+// (The first version -- one thread per column looping over ~1000 partials -- ran on 3 CUs and cost 44 % of
+// the step: profiles/r01a_first_run_kernel_stats.csv.)
+struct ReduceOut { float* o[3]; };
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ partials, long pstride, int np, int per_group,
-                                                        float* __restrict__ out, long ostride, int ncol, float scale, int accumulate) {
+                                                        ReduceOut out, long ostride, int w, int nseg, int accumulate) {
   __shared__ float red[8][33];
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + c;
+  const int seg = blockIdx.z;
+  const int col = blockIdx.x * 32 + c;             // column inside the segment
   const int p0 = blockIdx.y * per_group, p1 = min(np, p0 + per_group);
   float s = 0.f;
-  if (col < ncol)
-    for (int p = p0 + g; p < p1; p += 8) s += partials[(long)p * pstride + col];
+  if (col < w)
+    for (int p = p0 + g; p < p1; p += 8) s += partials[(long)p * pstride + seg * w + col];
   red[g][c] = s;
   __syncthreads();
-  if (g == 0 && col < ncol) {
+  if (g == 0 && col < w) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][c];
-    t *= scale;
-    float* o = out + (long)blockIdx.y * ostride + col;
+    // pass 1: one scratch row per group, all segments side by side; final pass: per-segment output
+    float* o = ostride != 0 ? out.o[0] + (long)blockIdx.y * ostride + seg * w + col : out.o[seg] + col;
     *o = accumulate ? *o + t : t;
   }
 }
 
-// scratch must hold 64 * ncol floats when np > 64
-static void launch_colreduce(const float* partials, long pstride, int np, float* out, int ncol, float scale, int accumulate,
+// scratch must hold 64 * nseg * w floats when np > 64
+static void launch_colreduce(const float* partials, long pstride, int np, ReduceOut out, int w, int nseg, int accumulate,
                              float* scratch, hipStream_t st) {
-  const int gx = (ncol + 31) / 32;
+  const int gx = (w + 31) / 32;
   if (np <= 64 || scratch == nullptr) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, st, partials, pstride, np, np, out, 0L, ncol, scale, accumulate);
+    hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1, nseg), dim3(256), 0, st, partials, pstride, np, np, out, 0L, w, nseg, accumulate);
     return;
   }
   const int per = (np + 63) / 64;
   const int ng = (np + per - 1) / per;
-  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, ng), dim3(256), 0, st, partials, pstride, np, per, scratch, (long)ncol, ncol, 1.f, 0);
-  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1), dim3(256), 0, st, scratch, (long)ncol, ng, ng, out, 0L, ncol, scale, accumulate);
+  ReduceOut tmp; tmp.o[0] = scratch; tmp.o[1] = tmp.o[2] = nullptr;
+  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, ng, nseg), dim3(256), 0, st, partials, pstride, np, per, tmp, (long)nseg * w, w, nseg, 0);
+  hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1, nseg), dim3(256), 0, st, scratch, (long)nseg * w, ng, ng, out, 0L, w, nseg, accumulate);
 }
 
 // column sums of a bf16 [M,N] matrix (bias grads): per-(slice) partials
@@ -604,12 +609,12 @@ extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamm
   return 0;
 }
 
-extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)row_grid(M, 1024) * 3 * d + 64L * d) * 4; }
+extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)row_grid(M, 1024) * 3 * d + 64L * 3 * d) * 4; }
 
 extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
-                                 const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
-                                 float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
-                                 long row_offset, float* workspace, hipStream_t st) {
+                                 const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                                 int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                                 unsigned site, long row_offset, float* workspace, hipStream_t st) {
   if (check_rows(M, d)) return 1;
   HRIEMO_CHECK(workspace != nullptr, "add_ln_bwd: workspace required");
   RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
@@ -621,9 +626,8 @@ extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, c
   HRIEMO_LAUNCH_CHECK("add_ln_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, 5.0 * M * d * 2);
   float* scratch = workspace + (long)nb * 3 * d;
-  launch_colreduce(workspace, (long)3 * d, nb, dgamma, d, 1.f, 0, scratch, st);
-  launch_colreduce(workspace + d, (long)3 * d, nb, dbeta, d, 1.f, 0, scratch, st);
-  if (dbias != nullptr) launch_colreduce(workspace + 2 * d, (long)3 * d, nb, dbias, d, 1.f, 0, scratch, st);
+  ReduceOut ro; ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = dbias;
+  launch_colreduce(workspace, (long)3 * d, nb, ro, d, dbias != nullptr ? 3 : 2, accumulate, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
 }
@@ -644,7 +648,8 @@ extern "C" int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* 
   const int slices = colsum_slices(M, N);
   const int rps = (M + slices - 1) / slices;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ncg, slices), dim3(64), 0, st, (const bf16_t*)X, ldx, M, N, rps, workspace);
-  launch_colreduce(workspace, (long)N, slices, out, N, 1.f, accumulate, workspace + (long)slices * N, st);
+  ReduceOut ro; ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
+  launch_colreduce(workspace, (long)N, slices, ro, N, 1, accumulate, workspace + (long)slices * N, st);
   HRIEMO_LAUNCH_CHECK("colsum");
   return 0;
 }
@@ -774,7 +779,7 @@ extern "C" int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, cons
   return 0;
 }
 
-extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return ((long)B * ((L + 31) / 32) * 2 * d + 64L * d) * 4; }
+extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return ((long)B * ((L + 31) / 32) * 2 * d + 64L * 2 * d) * 4; }
 
 extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                                   const void* X, const float* gamma, const float* mean, const float* rstd, void* dX,
@@ -789,8 +794,8 @@ extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is
   HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (2.0 * B * L + (double)B * Lf) * d * 2);
   float* scratch = workspace + (long)B * nc * 2 * d;
-  launch_colreduce(workspace, (long)2 * d, B * nc, dgamma, d, 1.f, 0, scratch, st);
-  launch_colreduce(workspace + d, (long)2 * d, B * nc, dbeta, d, 1.f, 0, scratch, st);
+  ReduceOut ro; ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = nullptr;
+  launch_colreduce(workspace, (long)2 * d, B * nc, ro, d, 2, 0, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
 }

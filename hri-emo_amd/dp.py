@@ -44,6 +44,7 @@ class GradBuckets:
         if overlap and self.world > 1:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                p._hriemo_grad_ready = self._on_grad     # gradients the kernels accumulate in place (_ops.GradSink)
 
     # -- hooks ---------------------------------------------------------------------------------
     def _launch(self, bi):

@@ -71,15 +71,16 @@ int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const un
 /* ---- y = LayerNorm(x + dropout(g)), eps, affine (X may be NULL: plain LayerNorm of g).
  * Replaces norm(h + self.dropout(sub(h))) (cross_modal_block_tacfn.py:81,92,105,106,118,119;
  * emotion_decoder.py:43,55,59).  bwd writes dX (residual branch), dG (sub-layer branch, dropout mask
- * applied) and the column sums dgamma, dbeta, dbias (= colsum dG, the producing Linear's bias grad). */
+ * applied) and the column sums dgamma, dbeta, dbias (= colsum dG, the producing Linear's bias grad);
+ * accumulate=1 adds them into the destination (fused accumulation into existing .grad buffers). */
 int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
                       float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
                       const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);
 long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
 int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
-                      const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int M, int d,
-                      float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
-                      long row_offset, float* workspace, hriemo_stream_t stream);
+                      const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                      int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                      unsigned site, long row_offset, float* workspace, hriemo_stream_t stream);
 
 /* ---- small glue on the path */
 long hriemo_colsum_workspace_bytes(int M, int N);

@@ -238,3 +238,31 @@ def test_full_size_cfg2_properties(H):
     O.train_step_loss(logits, beta, y).backward()
     for n, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
+
+
+def test_fused_weight_grad_accumulation_matches_autograd_path(H):
+    """Parameter gradients written straight into pre-existing .grad buffers (_ops.GradSink: GEMM/column-
+    reduce accumulate) equal the ones autograd accumulates from returned tensors, and really accumulate."""
+    from hri_emo_amd.dp import GradBuckets
+    torch.manual_seed(5)
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(6, 40, 24, 128, 21)
+    args = (cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    y = (torch.rand(6, 4, device="cuda") < 0.3).float()
+
+    def step():
+        logits, beta, _ = m(*args)
+        O.train_step_loss(logits, beta, y).backward()
+
+    step()                                                   # p.grad is None -> tensors returned to autograd
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    buckets = GradBuckets(m.parameters())                    # flat fp32 buffer, p.grad are views into it
+    buckets.zero_grad()
+    step()                                                   # fused: kernels accumulate in place
+    for n, p in m.named_parameters():
+        assert p.grad.data_ptr() >= buckets.flat.data_ptr(), n
+        assert torch.equal(p.grad, ref[n]), (n, (p.grad - ref[n]).abs().max().item())
+    step()                                                   # no zeroing: must now hold twice the gradient
+    for n, p in m.named_parameters():
+        err = (p.grad - 2 * ref[n]).abs().max().item()
+        assert err <= 1e-5 * max(1.0, ref[n].abs().max().item()), (n, err)
