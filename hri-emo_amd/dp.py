@@ -20,17 +20,20 @@ class GradBuckets:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         order = list(reversed(self.params))
-        total = sum(p.numel() for p in order)
+        pad = lambda n: (n + 63) // 64 * 64          # every view starts 256-B aligned (16-B vector stores)
+        total = sum(pad(p.numel()) for p in order)
         dev = order[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.buckets = []           # (start, end, n_params)
         self._bucket_of = {}
+        self._offsets = {}
         off, b_start, b_n = 0, 0, 0
         for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            self._offsets[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
-            off += n
+            off += pad(n)
             b_n += 1
             if (off - b_start) * 4 >= bucket_bytes:
                 self.buckets.append((b_start, off, b_n))
@@ -60,12 +63,10 @@ class GradBuckets:
 
     # -- per-step API --------------------------------------------------------------------------
     def _rebind(self):
-        off = 0
-        for p in reversed(self.params):
-            n = p.numel()
+        for p in self.params:
+            off, n = self._offsets[id(p)], p.numel()
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * 4:
                 p.grad = self.flat[off:off + n].view_as(p)
-            off += n
 
     def zero_grad(self):
         self.flat.zero_()
