@@ -16,6 +16,8 @@
 //    ds_read_b128 row reads and the transposed reads (8 consecutive rows -> 8 distinct 32-B windows).
 //  * key-padding mask = additive -inf; a row whose keys are all PAD yields NaN like the reference.
 //  * attention dropout is replayed from a counter hash (common.h), nothing is stored.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct AttnArgs {
@@ -35,6 +37,8 @@ struct AttnArgs {
   const unsigned long long* seed_dev;
 };
 
+// v_exp_f32 directly: arguments are <= 0 (or -inf), no denormal-range fix-up needed
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
@@ -80,6 +84,35 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16_t* base, long l
   }
 }
 
+// Register-staged variant (T14 split): fetch = issue the global loads of a tile into registers,
+// commit = write them to LDS after the barrier.  The fetch of tile t+1 is issued right after tile t has
+// been committed, so its HBM/L2 latency hides under tile t's MFMA + softmax work.
+template <int HD, int NR, int NT> struct TileRegs {
+  static constexpr int NPT = (NR * AttnGeom<HD>::CHP + NT - 1) / NT;
+  bf16x8 v[NPT];
+};
+template <int HD, int NR, int NT>
+__device__ __forceinline__ void tile_fetch(TileRegs<HD, NR, NT>& t, const bf16_t* base, long ld, int row_first, int nrows_total, int tid) {
+  using G = AttnGeom<HD>;
+#pragma unroll
+  for (int k = 0; k < TileRegs<HD, NR, NT>::NPT; ++k) {
+    const int id = tid + k * NT;
+    const int r = id / G::CHP, c = id - r * G::CHP;
+    t.v[k] = zero8();
+    if (id < NR * G::CHP && row_first + r < nrows_total && c < G::CH) t.v[k] = *(const bf16x8*)(base + (long)(row_first + r) * ld + c * 8);
+  }
+}
+template <int HD, int NR, int NT>
+__device__ __forceinline__ void tile_commit(const TileRegs<HD, NR, NT>& t, char* tile, int tid) {
+  using G = AttnGeom<HD>;
+#pragma unroll
+  for (int k = 0; k < TileRegs<HD, NR, NT>::NPT; ++k) {
+    const int id = tid + k * NT;
+    const int r = id / G::CHP, c = id - r * G::CHP;
+    if (id < NR * G::CHP) *(LDS_PTR(bf16x8))(tile + r * G::STRIDE + c * 16) = t.v[k];
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int HD, int NW, int QW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
@@ -119,16 +152,31 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
   const int nkt = (a.Lk + 63) >> 6;
 
+  constexpr bool PF = false;              // measured: the prefetch helps dQ / dK,dV (-25 %) but not the forward
+  TileRegs<HD, 64, NT> kr, vr;
+  if (PF) {
+    tile_fetch<HD, 64, NT>(kr, Kb, a.ldk, 0, a.Lk, tid);
+    tile_fetch<HD, 64, NT>(vr, Vb, a.ldv, 0, a.Lk, tid);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    load_tile<HD, 64, NT>(Kt, Kb, a.ldk, kt * 64, a.Lk, tid);
-    load_tile<HD, 64, NT>(Vt, Vb, a.ldv, kt * 64, a.Lk, tid);
+    if (PF) {
+      tile_commit<HD, 64, NT>(kr, Kt, tid);
+      tile_commit<HD, 64, NT>(vr, Vt, tid);
+    } else {
+      load_tile<HD, 64, NT>(Kt, Kb, a.ldk, kt * 64, a.Lk, tid);
+      load_tile<HD, 64, NT>(Vt, Vb, a.ldv, kt * 64, a.Lk, tid);
+    }
     if (tid < 64) {
       const int key = kt * 64 + tid;
       const bool pad = key >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
       mb[tid] = pad ? -INFINITY : 0.f;
     }
     __syncthreads();
+    if (PF && kt + 1 < nkt) {
+      tile_fetch<HD, 64, NT>(kr, Kb, a.ldk, (kt + 1) * 64, a.Lk, tid);
+      tile_fetch<HD, 64, NT>(vr, Vb, a.ldv, (kt + 1) * 64, a.Lk, tid);
+    }
 
     f32x4 s[QW][4];
 #pragma unroll
@@ -160,14 +208,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(m[qs], mx);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = exp2f(m[qs] - msafe);
+      const float alpha = EXP2(m[qs] - msafe);
       m[qs] = mnew;
       float rs = 0.f;
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[qs][n][r] - msafe);
+          const float p = EXP2(s[qs][n][r] - msafe);
           s[qs][n][r] = p;
           rs += p;
         }
@@ -278,16 +326,31 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
   const int nkt = (a.Lk + 63) >> 6;
 
+  constexpr bool PF = (NW == 4) && (HD <= 96);     // hd=128 has no registers left for the staging set
+  TileRegs<HD, 64, NT> kr, vr;
+  if (PF) {
+    tile_fetch<HD, 64, NT>(kr, Kb, a.ldk, 0, a.Lk, tid);
+    tile_fetch<HD, 64, NT>(vr, Vb, a.ldv, 0, a.Lk, tid);
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    load_tile<HD, 64, NT>(Kt, Kb, a.ldk, kt * 64, a.Lk, tid);
-    load_tile<HD, 64, NT>(Vt, Vb, a.ldv, kt * 64, a.Lk, tid);
+    if (PF) {
+      tile_commit<HD, 64, NT>(kr, Kt, tid);
+      tile_commit<HD, 64, NT>(vr, Vt, tid);
+    } else {
+      load_tile<HD, 64, NT>(Kt, Kb, a.ldk, kt * 64, a.Lk, tid);
+      load_tile<HD, 64, NT>(Vt, Vb, a.ldv, kt * 64, a.Lk, tid);
+    }
     if (tid < 64) {
       const int key = kt * 64 + tid;
       const bool pad = key >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
       mb[tid] = pad ? -INFINITY : 0.f;
     }
     __syncthreads();
+    if (PF && kt + 1 < nkt) {
+      tile_fetch<HD, 64, NT>(kr, Kb, a.ldk, (kt + 1) * 64, a.Lk, tid);
+      tile_fetch<HD, 64, NT>(vr, Vb, a.ldv, (kt + 1) * 64, a.Lk, tid);
+    }
 
     f32x4 s[QW][4], dp[QW][4];
 #pragma unroll
@@ -317,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
         const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[qs][n][r] * sl2 + bias[r] - lse2[qs]);
+          const float p = EXP2(s[qs][n][r] * sl2 + bias[r] - lse2[qs]);
           float dpd = dp[qs][n][r];
           if (a.thr16 != 0) {
             const uint32_t key = (uint32_t)(kt * 64 + n * 16 + 4 * g + r);
@@ -403,16 +466,31 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   const long lbase = ((long)b * a.H + h) * a.Lq;
   const int nqt = (a.Lq + 31) >> 5;
 
+  constexpr bool PF = (NW == 4);
+  TileRegs<HD, 32, NT> qr, dor;
+  if (PF) {
+    tile_fetch<HD, 32, NT>(qr, Qb, a.ldq, 0, a.Lq, tid);
+    tile_fetch<HD, 32, NT>(dor, dOb, a.lddo, 0, a.Lq, tid);
+  }
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
-    load_tile<HD, 32, NT>(Qt, Qb, a.ldq, qt * 32, a.Lq, tid);
-    load_tile<HD, 32, NT>(dOt, dOb, a.lddo, qt * 32, a.Lq, tid);
+    if (PF) {
+      tile_commit<HD, 32, NT>(qr, Qt, tid);
+      tile_commit<HD, 32, NT>(dor, dOt, tid);
+    } else {
+      load_tile<HD, 32, NT>(Qt, Qb, a.ldq, qt * 32, a.Lq, tid);
+      load_tile<HD, 32, NT>(dOt, dOb, a.lddo, qt * 32, a.Lq, tid);
+    }
     if (tid < 32) {
       const int q = qt * 32 + tid;
       lse_s[tid] = q < a.Lq ? a.lse[lbase + q] * LOG2E : INFINITY;   // +inf -> p = 0 for rows past Lq
       del_s[tid] = q < a.Lq ? a.delta[lbase + q] : 0.f;
     }
     __syncthreads();
+    if (PF && qt + 1 < nqt) {
+      tile_fetch<HD, 32, NT>(qr, Qb, a.ldq, (qt + 1) * 32, a.Lq, tid);
+      tile_fetch<HD, 32, NT>(dor, dOb, a.lddo, (qt + 1) * 32, a.Lq, tid);
+    }
 
     f32x4 s[KW][2], dp[KW][2];
 #pragma unroll
@@ -444,7 +522,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
         const uint32_t key = (uint32_t)(kbase + kw * 16 + i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = kvalid[kw] ? exp2f(s[kw][qs][r] * sl2 - lse4[r]) : 0.f;
+          float p = kvalid[kw] ? EXP2(s[kw][qs][r] * sl2 - lse4[r]) : 0.f;
           float pd = p, dpd = dp[kw][qs][r];
           if (a.thr16 != 0) {
             const uint32_t q = (uint32_t)(qt * 32 + qs * 16 + 4 * g + r);
@@ -543,6 +621,14 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ host
+// Sub-tiles per wave.  Measured on cfg 2 (profiles/): the forward is fastest with two 16-row query sub-tiles
+// per wave (K/V fragment reuse), the backward kernels with one (128 instead of ~220 VGPRs -> twice the
+// waves per SIMD to cover their long VALU chains, and less padding waste at L=400).
+static int attn_wide(int backward) {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("HRIEMO_ATTN_WIDE_BWD"); v = (e && e[0] == '1') ? 1 : 0; }
+  return backward ? v : 1;
+}
 static int check_common(const AttnArgs& a, int hd) {
   HRIEMO_CHECK(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "attn: empty problem");
   HRIEMO_CHECK(hd == 16 || hd == 32 || hd == 64 || hd == 96 || hd == 128, "attn: head_dim %d not built (16/32/64/96/128)", hd);
@@ -578,7 +664,7 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   if (check_common(a, head_dim)) return 1;
   HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: unaligned O");
   hriemo_prof_begin(HP_ATTN_FWD, st);
-  if (Lq > 64) {
+  if (Lq > 64 && attn_wide(0)) {
 #define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 2>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
@@ -615,7 +701,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
                    ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0, "attn_bwd: unaligned operand");
   hriemo_prof_begin(HP_ATTN_BWD_DQ, st);
-  if (Lq > 64) {
+  if (Lq > 64 && attn_wide(1)) {
 #define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
@@ -631,7 +717,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_LAUNCH_CHECK("attn_bwd_dq_kernel");
   hriemo_prof_end(HP_ATTN_BWD_DQ, st, 6.0 * B * H * (double)Lq * Lk * head_dim);
   hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
-  if (Lk > 64) {
+  if (Lk > 64 && attn_wide(1)) {
 #define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2>), dim3((Lk + 127) / 128, B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
