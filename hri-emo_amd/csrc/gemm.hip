@@ -141,6 +141,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
   operand_offsets<TB, BN, B_PW>(boff, p.ldb, n0, p.N, wave, lane);
 
   auto stage = [&](int s, int kstep) {
+#if defined(HRIEMO_GEMM_ABL) && (HRIEMO_GEMM_ABL & 1)
+    if (kstep >= NS - 1) return;        // timing-only build: prologue stages only
+#endif
     char* sa = smem + s * STAGE;
     const int krem = kend - kbeg - kstep * 64;
     stage_operand<TA, BM, A_PW>(sa, abase + kstep * astep, aoff, krem, wave, lane);
@@ -153,7 +156,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#if defined(HRIEMO_GEMM_ABL)
+  int abl_nfrag = 0;
+#endif
   auto load_frags = [&](const char* sa, int ks, bf16x8 (&af)[MT], bf16x8 (&bfr)[NTL]) {
+#if defined(HRIEMO_GEMM_ABL) && (HRIEMO_GEMM_ABL & 2)
+    if (abl_nfrag >= 2) {               // timing-only build: keep the first two fragment sets, keep them live
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(af[mi]));
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) asm volatile("" : "+v"(bfr[ni]));
+      return;
+    }
+    ++abl_nfrag;
+#endif
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -163,7 +179,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
       bfr[ni] = TB == 0 ? lds_row_frag(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
   };
   auto mma_rows = [&](const bf16x8 (&af)[MT], const bf16x8 (&bfr)[NTL], int lo, int hi) {
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
       if (mi >= lo && mi < hi) {
@@ -171,7 +186,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
         for (int ni = 0; ni < NTL; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
       }
-    __builtin_amdgcn_s_setprio(0);
   };
   auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bfr)[NTL]) { mma_rows(af, bfr, 0, MT); };
 
@@ -223,32 +237,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
     // so every fragment read has >= half a cluster of MFMAs to land, and the LDS-read retire before the
     // barrier is a builtin s_waitcnt (lgkmcnt(0) only) the compiler can see, so it adds no wait of its own
     // in front of the B cluster.
+    // fragment reads of the NEXT half-step are interleaved with the MFMAs of the current one in four
+    // equal groups (sched_group_barrier), so the LDS sees a steady trickle instead of 8 waves bursting
+    // 12 reads each right after the barrier.
+    constexpr int RD_A = (TA == 0 ? 1 : 2) * MT, RD_B = (TB == 0 ? 1 : 2) * NTL;     // ds_read instrs per set
+    auto interleave = [&]() {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NTL / 4, 0);               // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, (RD_A + RD_B + 3) / 4, 0);      // DS read
+      }
+    };
+    // 64x64 wave tiles have the registers for it (<= 16 accumulator tiles); the 128x64 wave tile of the
+    // 256x256 block is at the 256-VGPR limit and keeps the coarser split below.
+    constexpr bool ILV = (MT * NTL <= 16);
     if (nk > 0) load_frags(smem, 0, afA, bfA);
     for (int it = 0; it < nk; ++it) {
       if (it + NS - 1 < nk) stage(nxt, it + NS - 1);
       __builtin_amdgcn_sched_barrier(0);
-      mma_rows(afA, bfA, 0, MT / 2);
-      __builtin_amdgcn_sched_barrier(0);
-      load_frags(smem + cur * STAGE, 1, afB, bfB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_rows(afA, bfA, MT / 2, MT);
+      if (ILV) {
+        load_frags(smem + cur * STAGE, 1, afB, bfB);
+        mma(afA, bfA);
+        interleave();
+      } else {
+        __builtin_amdgcn_s_setprio(1);
+        mma_rows(afA, bfA, 0, MT / 2);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(smem + cur * STAGE, 1, afB, bfB);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_rows(afA, bfA, MT / 2, MT);
+        __builtin_amdgcn_s_setprio(0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      if (it + 1 < nk) {
+      const bool more = it + 1 < nk;
+      if (more) {
         // stage it+1 must have landed for every wave; our own reads of stage `it` must be retired before any
         // wave may restage that slot (WAR).
         if (it + NS - 1 < nk) wait_vmcnt<(NS - 2) * LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone
         __builtin_amdgcn_s_barrier();
-        load_frags(smem + cur * STAGE, 0, afA, bfA);
+        if (ILV) {                                // reads + MFMAs in ONE scheduling region
+          __builtin_amdgcn_sched_barrier(0);
+          load_frags(smem + cur * STAGE, 0, afA, bfA);
+          mma(afB, bfB);
+          interleave();
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          load_frags(smem + cur * STAGE, 0, afA, bfA);
+        }
       } else {
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (ILV) {
+          __builtin_amdgcn_sched_barrier(0);
+          mma(afB, bfB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      mma(afB, bfB);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!ILV) {                                 // big tile: one merged copy of the cluster (register budget)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(afB, bfB);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   __syncthreads();                    // everyone is done with the ring before it becomes the C staging area
