@@ -145,7 +145,8 @@ class DataParallelStep:
         graph = torch.cuda.CUDAGraph()
         _ops.CAPTURING = True
         try:
-            with torch.cuda.graph(graph):
+            # thread_local: the RCCL watchdog thread may query events while we capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 _ops.bump_seed_word(self._static[0].device)
                 self._static_loss = self._fwd_bwd(*self._static)
         finally:
