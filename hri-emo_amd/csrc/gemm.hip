@@ -404,6 +404,7 @@ static const TileCfg kCfg[] = {
     {128, 256, 512, 3 * 49152},   // 5: 128x256, 2x4 waves, 3 stages
     {256, 128, 512, 3 * 49152},   // 6: 256x128, 4x2 waves, 3 stages, staggered S/M phases
     {128, 256, 512, 3 * 49152},   // 7: 128x256, 2x4 waves, 3 stages, staggered S/M phases
+    {64, 128, 256, 2 * 24576},    // 8: 64x128, 2x2 waves (32x64 per wave), 2 stages: small-M problems
 };
 static const int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 static int g_force_cfg = -1;
@@ -434,7 +435,8 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     case 4: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 2>(a, lds, st); break;
     case 5: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3>(a, lds, st); break;
     case 6: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3, 1>(a, lds, st); break;
-    default: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3, 1>(a, lds, st); break;
+    case 7: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3, 1>(a, lds, st); break;
+    default: launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 2>(a, lds, st); break;
   }
 }
 
@@ -444,7 +446,7 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
 static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (ta == 1) return (M >= 512 && N >= 512 && (long)K >= 4096) ? 3 : 0;     // dW: split-K fills the chip
-  if (M < 1024 || N < 256) return 0;                                          // decoder / gate sized problems
+  if (M < 1024 || N < 256) return (M <= 512 && N >= 256) ? 8 : 0;             // decoder / gate sized problems
   if (tb == 0) return (N >= 2048 && M >= 16384) ? 3 : 7;                      // NT: 256x256, else staggered 128x256
   return M >= 16384 ? 3 : 4;                                                  // NN
 }
@@ -465,7 +467,8 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   HRIEMO_CHECK(!(c_is_f32 && epilogue != 0), "gemm: fp32 output has no activation epilogue");
   HRIEMO_CHECK(c_is_f32 || !accumulate, "gemm: accumulate needs fp32 output");
 
-  const int cfg = pick_config(ta, tb, M, N, K);
+  int cfg = pick_config(ta, tb, M, N, K);
+  if (cfg == 8 && ta == 1) cfg = 0;            // the 64-row tile has no K-strided A image (128-B rows cannot hold the swizzle)
   GemmArgs a;
   a.M = M; a.N = N; a.K = K;
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb;

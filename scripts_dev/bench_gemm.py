@@ -30,12 +30,12 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3   # us
-shapes_nt = [(25600, 3072, 768), (25600, 2304, 768), (25600, 768, 768), (25600, 768, 3072), (25600, 1536, 768), (8192, 768, 768), (8192, 3072, 768), (8192, 2304, 768)]
-shapes_nn = [(25600, 768, 3072), (25600, 3072, 768), (25600, 768, 768), (25600, 768, 2304), (8192, 768, 768), (8192, 768, 3072)]   # (M, Kout, Nred)
+shapes_nt = [(384, 768, 768), (384, 2304, 768), (384, 2048, 768), (384, 768, 2048), (64, 256, 3072), (25600, 3072, 768), (25600, 2304, 768), (25600, 768, 768), (25600, 768, 3072), (25600, 1536, 768), (8192, 768, 768), (8192, 3072, 768), (8192, 2304, 768)]
+shapes_nn = [(384, 768, 2304), (384, 2048, 768), (384, 768, 2048), (25600, 768, 3072), (25600, 3072, 768), (25600, 768, 768), (25600, 768, 2304), (8192, 768, 768), (8192, 768, 3072)]   # (M, Kout, Nred)
 shapes_tn = [(3072, 768, 25600), (768, 3072, 25600), (768, 768, 25600), (2304, 768, 25600), (768, 768, 8192), (3072, 768, 8192)]      # (Nout, Kout, Mred)
 torch.manual_seed(0)
 res = {}
-ncfg = int(os.environ.get("NCFG", "6"))
+ncfg = int(os.environ.get("NCFG", "9"))
 for cfg in range(ncfg):
     ok, info = check(cfg)
     print(f"cfg {cfg}: exact={ok} {info or ''}", flush=True)
