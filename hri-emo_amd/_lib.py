@@ -16,19 +16,19 @@ _SIGS = {
     "hriemo_attn_fwd": ("plplplplppiiiiifQpIip", "i"),
     "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIip", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
-    "hriemo_add_ln_fwd": ("pppppppiiffQpIlp", "i"),
+    "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),
-    "hriemo_add_ln_bwd": ("pppppppppppiiifQpIlpp", "i"),
+    "hriemo_add_ln_bwd": ("ppppppppppppiiifQpIlpp", "i"),
     "hriemo_colsum_workspace_bytes": ("ii", "l"),
     "hriemo_colsum_bf16": ("pliipipp", "i"),
     "hriemo_cast_f32_to_bf16": ("pplp", "i"),
     "hriemo_cast_bf16_to_f32": ("pplp", "i"),
     "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
     "hriemo_expand_rows": ("ppilp", "i"),
-    "hriemo_rowdot_fwd": ("ppppiip", "i"),
-    "hriemo_rowdot_bwd": ("ppppppiip", "i"),
+    "hriemo_rowdot_fwd": ("pppppiip", "i"),
+    "hriemo_rowdot_bwd": ("pppppppiip", "i"),
     "hriemo_pool_chunks": ("i", "i"),
-    "hriemo_ln_pool_fwd": ("ppppppppiiiifp", "i"),
+    "hriemo_ln_pool_fwd": ("pppppppppiiiifp", "i"),
     "hriemo_gate_input": ("ppppiiiipppp" + "p", "i"),
     "hriemo_sigmoid_beta": ("pppiip", "i"),
     "hriemo_fuse_fwd": ("ppppiiip", "i"),
@@ -36,7 +36,7 @@ _SIGS = {
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),
     "hriemo_gate_input_bwd": ("ppppppiip", "i"),
     "hriemo_ln_pool_bwd_workspace_bytes": ("iii", "l"),
-    "hriemo_ln_pool_bwd": ("pipippppppppp" + "iiipp", "i"),
+    "hriemo_ln_pool_bwd": ("pipipppppppppp" + "iiipp", "i"),
     "hriemo_prof_enable": ("i", "i"),
     "hriemo_prof_nclass": ("", "i"),
     "hriemo_prof_collect": ("ippp", "i"),

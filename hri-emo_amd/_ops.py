@@ -212,17 +212,20 @@ def attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off):
     return out
 
 
-def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off):
+def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False):
+    """y = LN(x + drop(g)); x32 = fp32 twin of the residual stream (used instead of x when given);
+    want32 -> also return the fp32 twin of y."""
     M, d = g.shape
     y = torch.empty((M, d), dtype=BF16, device=g.device)
+    y32 = torch.empty((M, d), dtype=torch.float32, device=g.device) if want32 else None
     mean = torch.empty(M, dtype=torch.float32, device=g.device)
     rstd = torch.empty(M, dtype=torch.float32, device=g.device)
-    _lib.call("hriemo_add_ln_fwd", _p(g), _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, _EPS, float(p),
-              seed, _p(seed_word(g.device)), site, row_off, _stream())
-    return y, mean, rstd
+    _lib.call("hriemo_add_ln_fwd", _p(g), _p(x), _p(x32), _p(gamma), _p(beta), _p(y), _p(y32), _p(mean), _p(rstd), M, d,
+              _EPS, float(p), seed, _p(seed_word(g.device)), site, row_off, _stream())
+    return y, y32, mean, rstd
 
 
-def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True, outs=None, accumulate=False):
+def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True, outs=None, accumulate=False, x32=None):
     """outs = (dgamma, dbeta, dbias) destination tensors (fp32 [d]); fresh ones when None."""
     M, d = g.shape
     dev = g.device
@@ -232,12 +235,42 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
         stats = torch.empty((3, d), dtype=torch.float32, device=dev)
         outs = (stats[0], stats[1], stats[2])
     ws = workspace(_lib.lib().hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
-    _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
+    _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
               _p(outs[1]), _p(outs[2]), int(accumulate), M, d, float(p), seed, _p(seed_word(dev)), site, row_off,
               _p(ws), _stream())
     if dg is None:
         dg = dx           # no dropout: both branches get the same gradient
     return dx, dg, outs[0], outs[1], outs[2]
+
+
+import os as _os
+TWIN = _os.environ.get("HRIEMO_FP32_TWIN", "1") != "0"      # carry the fp32 twin of the residual stream (LayerNorm outputs)
+
+
+def as_pair(x):
+    """(bf16 copy for the GEMMs, fp32 twin for the residual path or None)"""
+    if x.dtype == BF16:
+        return x, None
+    return x.to(BF16), (x if x.dtype == torch.float32 else x.float()) if TWIN else None
+
+
+def from_pair(y16, y32, dtype):
+    if dtype == BF16:
+        return y16
+    return (y32 if y32 is not None else y16).to(dtype)
+
+
+def _sum_grads(d16, d32):
+    """total upstream gradient of a (bf16, fp32-twin) output pair, as bf16"""
+    if d32 is None:
+        return d16
+    if d16 is None:
+        return d32.to(BF16)
+    return (d16.float() + d32).to(BF16)
+
+
+def _c32(t):
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
 
 
 def _heads(d, H):
@@ -259,38 +292,41 @@ class SelfAttnLN(torch.autograd.Function):
     """y = LN(x + drop(out_proj(MHA_core(in_proj(x))))) ; returns (y, probs|None)"""
 
     @staticmethod
-    def forward(ctx, x, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+    def forward(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
         B, L, d = x.shape
         hd = _heads(d, H)
         M = B * L
         x2 = _contig_bf16(x).view(M, d)
+        x32 = _c32(x32)
+        x32v = x32.view(M, d) if x32 is not None else None
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         qkv = linear_fwd(x2, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off)
         g = linear_fwd(o, w_out16, b_out)
-        y, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L)
+        y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
-        ctx.save_for_backward(x2, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
+        ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
-        return y.view(B, L, d), probs
+        return y.view(B, L, d), (y32.view(B, L, d) if y32 is not None else None), probs
 
     @staticmethod
-    def backward(ctx, dy, _dprobs):
-        x2, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
+    def backward(ctx, dy, dy32, _dprobs):
+        x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
         B, L, d, H, hd, p, seed, site, b_off = ctx.cfg
         M = B * L
         dev = x2.device
-        dy2 = _contig_bf16(dy).view(M, d)
+        dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(M, d)
         p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
         ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L,
                                                    outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
-                                                   accumulate=acc)
+                                                   accumulate=acc, x32=x32v)
         dw_out = sink.buf(p_w_out)
         linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
@@ -304,19 +340,22 @@ class SelfAttnLN(torch.autograd.Function):
         dx = linear_dx(dqkv, w_in16, epi=3, aux=ds)
         sink.done()
         r = sink.ret
-        return (dx.view(B, L, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8
+        return (dx.view(B, L, d), None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8
 
 
 class CrossAttnLN(torch.autograd.Function):
     """y = LN(xq + drop(out_proj(MHA_core(Wq xq, Wkv xkv)))) ; returns (y, probs|None)"""
 
     @staticmethod
-    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+    def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(xq)
         B, Lq, d = xq.shape
         Lk = xkv.shape[1]
         hd = _heads(d, H)
         xq2 = _contig_bf16(xq).view(B * Lq, d)
+        xq32 = _c32(xq32)
+        x32v = xq32.view(B * Lq, d) if xq32 is not None else None
         xkv2 = _contig_bf16(xkv).view(B * Lk, d)
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         q = linear_fwd(xq2, w_in16[:d], b_in[:d])
@@ -324,26 +363,26 @@ class CrossAttnLN(torch.autograd.Function):
         k, v = kv[:, :d], kv[:, d:]
         o, lse = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off)
         g = linear_fwd(o, w_out16, b_out)
-        y, mean, rstd = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq)
+        y, y32, mean, rstd = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN)
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
-        ctx.save_for_backward(xq2, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
+        ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
-        return y.view(B, Lq, d), probs
+        return y.view(B, Lq, d), (y32.view(B, Lq, d) if y32 is not None else None), probs
 
     @staticmethod
-    def backward(ctx, dy, _dprobs):
-        xq2, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
+    def backward(ctx, dy, dy32, _dprobs):
+        xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
         B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
         dev = xq2.device
-        dy2 = _contig_bf16(dy).view(B * Lq, d)
+        dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(B * Lq, d)
         p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
         ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * Lq,
                                                    outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
-                                                   accumulate=acc)
+                                                   accumulate=acc, x32=x32v)
         dw_out = sink.buf(p_w_out)
         linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
@@ -361,7 +400,7 @@ class CrossAttnLN(torch.autograd.Function):
         dxkv = linear_dx(dkv, w_in16[d:])
         sink.done()
         r = sink.ret
-        return (dxq.view(B, Lq, d), dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
+        return (dxq.view(B, Lq, d), None, dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
                 r(dbeta)) + (None,) * 8
 
 
@@ -369,11 +408,14 @@ class FFNLN(torch.autograd.Function):
     """y = LN(x + drop(W2 . drop_mid(relu(W1 x + b1)) + b2))"""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off):
+    def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off):
+        ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
         B, L, d = x.shape
         M = B * L
         x2 = _contig_bf16(x).view(M, d)
+        x32 = _c32(x32)
+        x32v = x32.view(M, d) if x32 is not None else None
         w1_16, w2_16 = sh.get(w1), sh.get(w2)
         h = linear_fwd(x2, w1_16, b1, relu=True)
         hd_ = h
@@ -382,25 +424,25 @@ class FFNLN(torch.autograd.Function):
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
         g = linear_fwd(hd_, w2_16, b2)
-        y, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L)
-        ctx.save_for_backward(x2, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
+        y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
+        ctx.save_for_backward(x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
         ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)
         ctx.params = (w1, b1, w2, b2, gamma, beta)
-        return y.view(B, L, d)
+        return y.view(B, L, d), (y32.view(B, L, d) if y32 is not None else None)
 
     @staticmethod
-    def backward(ctx, dy):
-        x2, h, hd_, g, mean, rstd, w1_16, w2_16, gamma = ctx.saved_tensors
+    def backward(ctx, dy, dy32):
+        x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma = ctx.saved_tensors
         B, L, d, p, p_mid, seed, site, b_off = ctx.cfg
         M, F = h.shape
         dev = x2.device
-        dy2 = _contig_bf16(dy).view(M, d)
+        dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(M, d)
         p_w1, p_b1, p_w2, p_b2, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
         ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L,
                                                 outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b2)),
-                                                accumulate=acc)
+                                                accumulate=acc, x32=x32v)
         dw2 = sink.buf(p_w2)
         linear_dw(dg, hd_, dw2, acc)
         da = linear_dx(dg, w2_16, epi=2, aux=h)          # * relu'(h)
@@ -414,15 +456,16 @@ class FFNLN(torch.autograd.Function):
         dx = linear_dx(da, w1_16, epi=3, aux=ds)
         sink.done()
         r = sink.ret
-        return (dx.view(B, L, d), r(dw1), r(db1), r(dw2), r(db2), r(dgamma), r(dbeta)) + (None,) * 6
+        return (dx.view(B, L, d), None, r(dw1), r(db1), r(dw2), r(db2), r(dgamma), r(dbeta)) + (None,) * 6
 
 
 class BetaGateFn(torch.autograd.Function):
     """(h_fusion, beta) = BetaGate(h_a, h_t, masks)  -- models/beta_gate_tacfn.py:68-118"""
 
     @staticmethod
-    def forward(ctx, h_a, h_t, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t):
+    def forward(ctx, h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t):
         _require_gpu(h_a)
+        h_a32, h_t32 = _c32(h_a32), _c32(h_t32)
         B, La, d = h_a.shape
         Lt = h_t.shape[1]
         L = La if La == Lt else Lt                      # :98-104 (align to the text length)
@@ -439,10 +482,10 @@ class BetaGateFn(torch.autograd.Function):
         mean_t, rstd_t = torch.empty(B * Lt, **f32), torch.empty(B * Lt, **f32)
         pa, pt = torch.empty((B, nca, d), **f32), torch.empty((B, nct, d), **f32)
         st = _stream()
-        _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa), B, La,
-                  L, d, _EPS, st)
-        _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt), B, Lt,
-                  L, d, _EPS, st)
+        _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(h_a32), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa),
+                  B, La, L, d, _EPS, st)
+        _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt),
+                  B, Lt, L, d, _EPS, st)
         gin = torch.empty((B, 4 * d), dtype=BF16, device=dev)
         a_pool, t_pool = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
         cnt = torch.empty((B, 2), **f32)
@@ -457,14 +500,14 @@ class BetaGateFn(torch.autograd.Function):
         H = torch.empty((B, L, d), dtype=BF16, device=dev)
         _lib.call("hriemo_fuse_fwd", _p(w), _p(An), _p(Tn), _p(H), B, L, d, st)
         ctx.save_for_backward(xa, xt, An, Tn, mean_a, rstd_a, mean_t, rstd_t, gin, a_pool, t_pool, cnt, hid, w, w1_16,
-                              w2_16, ga, gt, kpm_a, kpm_t)
+                              w2_16, ga, gt, kpm_a, kpm_t, h_a32, h_t32)
         ctx.cfg = (B, La, Lt, L, d)
         return H, beta
 
     @staticmethod
     def backward(ctx, dH, dbeta):
         (xa, xt, An, Tn, mean_a, rstd_a, mean_t, rstd_t, gin, a_pool, t_pool, cnt, hid, w, w1_16, w2_16, ga, gt, kpm_a,
-         kpm_t) = ctx.saved_tensors
+         kpm_t, h_a32, h_t32) = ctx.saved_tensors
         B, La, Lt, L, d = ctx.cfg
         dev = xa.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -494,11 +537,11 @@ class BetaGateFn(torch.autograd.Function):
         sa, st_ = torch.empty((2, d), **f32), torch.empty((2, d), **f32)
         ws = workspace(max(L_.hriemo_ln_pool_bwd_workspace_bytes(B, La, d),
                            L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d)), dev, slot=1)
-        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(ga), _p(mean_a), _p(rstd_a),
-                  _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
-        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(gt), _p(mean_t), _p(rstd_t),
-                  _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
-        return dxa, dxt, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
+        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a),
+                  _p(rstd_a), _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
+        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
+                  _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
+        return dxa, None, dxt, None, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
 
 
 class ExpandFn(torch.autograd.Function):
@@ -527,25 +570,27 @@ class RowDotFn(torch.autograd.Function):
     """logits[M] = z[M,d] . w[1,d] + b   (models/emotion_decoder.py:155)"""
 
     @staticmethod
-    def forward(ctx, z, w, b):
+    def forward(ctx, z, z32, w, b):
         _require_gpu(z)
         B, Ne, d = z.shape
         z2 = _contig_bf16(z).view(B * Ne, d)
+        z32 = _c32(z32)
+        z32v = z32.view(B * Ne, d) if z32 is not None else None
         wf = w.detach().float().contiguous()
         bf = b.detach().float().contiguous()
         out = torch.empty(B * Ne, dtype=torch.float32, device=z.device)
-        _lib.call("hriemo_rowdot_fwd", _p(z2), _p(wf), _p(bf), _p(out), B * Ne, d, _stream())
-        ctx.save_for_backward(z2, wf)
+        _lib.call("hriemo_rowdot_fwd", _p(z2), _p(z32v), _p(wf), _p(bf), _p(out), B * Ne, d, _stream())
+        ctx.save_for_backward(z2, z32v, wf)
         ctx.cfg = (B, Ne, d)
         return out.view(B, Ne)
 
     @staticmethod
     def backward(ctx, dl):
-        z2, wf = ctx.saved_tensors
+        z2, z32v, wf = ctx.saved_tensors
         B, Ne, d = ctx.cfg
         dl2 = dl.contiguous().float().view(-1)
         dz = torch.empty((B * Ne, d), dtype=BF16, device=z2.device)
         dw = torch.empty((1, d), dtype=torch.float32, device=z2.device)
         db = torch.empty(1, dtype=torch.float32, device=z2.device)
-        _lib.call("hriemo_rowdot_bwd", _p(dl2), _p(z2), _p(wf), _p(dz), _p(dw), _p(db), B * Ne, d, _stream())
-        return dz.view(B, Ne, d), dw, db
+        _lib.call("hriemo_rowdot_bwd", _p(dl2), _p(z2), _p(z32v), _p(wf), _p(dz), _p(dw), _p(db), B * Ne, d, _stream())
+        return dz.view(B, Ne, d), None, dw, db

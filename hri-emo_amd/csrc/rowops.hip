@@ -41,11 +41,25 @@ __device__ __forceinline__ void block_colsum(float* lds_row, const float (&acc)[
   }
 }
 
+// residual operand: the fp32 twin of the stream when given, else its bf16 copy, else 0
+__device__ __forceinline__ void load_resid(const bf16_t* X, const float* X32, long off, float* xf) {
+  if (X32 != nullptr) {
+    const f32x4 a = *(const f32x4*)(X32 + off), b = *(const f32x4*)(X32 + off + 4);
+    xf[0] = a[0]; xf[1] = a[1]; xf[2] = a[2]; xf[3] = a[3]; xf[4] = b[0]; xf[5] = b[1]; xf[6] = b[2]; xf[7] = b[3];
+  } else if (X != nullptr) {
+    bf8_to_f32(*(const bf16x8*)(X + off), xf);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xf[j] = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ y = LN(x + drop(g))
 template <int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ X,
-                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         bf16_t* __restrict__ Y, float* __restrict__ mean_o,
+                                                         const float* __restrict__ X32, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16_t* __restrict__ Y,
+                                                         float* __restrict__ Y32, float* __restrict__ mean_o,
                                                          float* __restrict__ rstd_o, int M, int d, float eps, RowDrop dr,
                                                          long row_offset) {
   const uint32_t key32 = row_key(dr);
@@ -61,12 +75,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
       if (ch < nchunk) {
         float gf[8], xf[8];
         bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
-        if (X != nullptr) bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), xf);
+        load_resid(X, X32, row * d + ch * 8, xf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float gv = gf[j];
           if (dr.thr16 != 0) gv = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? gv * dr.inv_keep : 0.f;
-          s[c][j] = (X != nullptr ? xf[j] : 0.f) + gv;
+          s[c][j] = xf[j] + gv;
           sum += s[c][j];
         }
       } else {
@@ -91,6 +105,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (s[c][j] - mu) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
         *(bf16x8*)(Y + row * d + ch * 8) = f32_to_bf8(o);
+        if (Y32 != nullptr) {
+          *(f32x4*)(Y32 + row * d + ch * 8) = (f32x4){o[0], o[1], o[2], o[3]};
+          *(f32x4*)(Y32 + row * d + ch * 8 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+        }
       }
     }
     if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
@@ -100,7 +118,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
 // backward: dS (residual grad), dG = dS * mask/(1-p); column partials of dgamma, dbeta, dbias(=colsum dG)
 template <int NCH>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ G,
-                                                         const bf16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                         const bf16_t* __restrict__ X, const float* __restrict__ X32,
+                                                         const float* __restrict__ gamma,
                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                          bf16_t* __restrict__ dX, bf16_t* __restrict__ dG,
                                                          float* __restrict__ partials, int M, int d, RowDrop dr,
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
       if (ch < nchunk) {
         float gf[8], xf[8], dyf[8];
         bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
-        if (X != nullptr) bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), xf);
+        load_resid(X, X32, row * d + ch * 8, xf);
         bf8_to_f32(*(const bf16x8*)(dY + row * d + ch * 8), dyf);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
             kp[c][j] = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16);
             gv = kp[c][j] ? gv * dr.inv_keep : 0.f;
           }
-          const float sv = (X != nullptr ? xf[j] : 0.f) + gv;
+          const float sv = xf[j] + gv;
           xh[c][j] = (sv - mu) * rstd;
           dyg[c][j] = dyf[j] * gamma[ch * 8 + j];
           c1 += dyg[c][j];
@@ -277,15 +296,15 @@ __global__ void expand_rows_kernel(const float* __restrict__ q, bf16_t* __restri
 }
 
 // logits[r] = z[r,:] . w + b   (emotion_decoder.py:155)
-__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restrict__ Z, const float* __restrict__ w, const float* __restrict__ b,
-                                                         float* __restrict__ out, int M, int d) {
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restrict__ Z, const float* __restrict__ Z32, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ out, int M, int d) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= M) return;
   float s = 0.f;
   for (int ch = lane; ch < (d >> 3); ch += 64) {
     float f[8];
-    bf8_to_f32(*(const bf16x8*)(Z + (long)row * d + ch * 8), f);
+    load_resid(Z, Z32, (long)row * d + ch * 8, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += f[j] * w[ch * 8 + j];
   }
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restric
   if (lane == 0) out[row] = s + (b != nullptr ? b[0] : 0.f);
 }
 // dZ[r,:] = dl[r]*w ; dw[e] = sum_r dl[r] z[r,e] ; db = sum_r dl[r]   (M is small: B*N_e)
-__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ Z32, const float* __restrict__ w,
                                                          bf16_t* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d) {
   __shared__ float red[8][33];
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -303,7 +322,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     const float wc = w[col];
     for (int r = g; r < M; r += 8) {
       const float gr = dl[r];
-      acc += gr * (float)Z[(long)r * d + col];
+      acc += gr * (Z32 != nullptr ? Z32[(long)r * d + col] : (float)Z[(long)r * d + col]);
       dZ[(long)r * d + col] = (bf16_t)(gr * wc);
       sb += gr;
     }
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
 // ------------------------------------------------------------------ beta gate
 // LayerNorm every row of X[b, :, :]; write the first Lkeep rows; pooled partial sums over valid rows.
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restrict__ X, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restrict__ X, const float* __restrict__ X32, const uint8_t* __restrict__ mask,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ Yn, float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                           float* __restrict__ partials, int L, int Lkeep, int d, float eps) {
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restri
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nchunk) {
-        bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), s[c]);
+        load_resid(X, X32, row * d + ch * 8, s[c]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sum += s[c][j];
       }
@@ -516,7 +535,7 @@ __global__ __launch_bounds__(256) void gate_input_bwd_kernel(const bf16_t* __res
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ w, int is_a,
                                                           const float* __restrict__ dpool, const uint8_t* __restrict__ mask,
-                                                          const bf16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                          const bf16_t* __restrict__ X, const float* __restrict__ X32, const float* __restrict__ gamma,
                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                           bf16_t* __restrict__ dX, float* __restrict__ partials, int L, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -540,7 +559,7 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
       const int ch = lane + 64 * c;
       if (ch < nchunk) {
         float xf[8], gh[8];
-        bf8_to_f32(*(const bf16x8*)(X + row * d + ch * 8), xf);
+        load_resid(X, X32, row * d + ch * 8, xf);
         if (dH != nullptr && l < Lf) bf8_to_f32(*(const bf16x8*)(dH + ((long)b * Lf + l) * d + ch * 8), gh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -595,23 +614,23 @@ static int check_rows(int M, int d) {
 }
 static int row_grid(int M, int cap) { int g = (M + 3) / 4; return g > cap ? cap : g; }
 
-extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
-                                 float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                                 float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
                                  const unsigned long long* seed_dev, unsigned site, long row_offset, hipStream_t st) {
   if (check_rows(M, d)) return 1;
   RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, gamma, beta, (bf16_t*)Y, mean, rstd, M, d, eps, dr, row_offset)
+#define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("add_ln_fwd_kernel");
-  hriemo_prof_end(HP_ROWOPS, st, (X ? 3.0 : 2.0) * M * d * 2);
+  hriemo_prof_end(HP_ROWOPS, st, ((X32 ? 3.0 : (X ? 2.0 : 1.0)) + 1.0 + (Y32 ? 2.0 : 0.0)) * M * d * 2);
   return 0;
 }
 
 extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)row_grid(M, 1024) * 3 * d + 64L * 3 * d) * 4; }
 
-extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
+extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
                                  const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
                                  int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
                                  unsigned site, long row_offset, float* workspace, hipStream_t st) {
@@ -620,7 +639,7 @@ extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, c
   RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
   const int nb = row_grid(M, 1024);
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((add_ln_bwd_kernel<N>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, (const bf16_t*)X, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
+#define CALL(N) hipLaunchKernelGGL((add_ln_bwd_kernel<N>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("add_ln_bwd_kernel");
@@ -692,16 +711,16 @@ extern "C" int hriemo_expand_rows(const float* q, void* out, int B, long n, hipS
   return 0;
 }
 
-extern "C" int hriemo_rowdot_fwd(const void* Z, const float* w, const float* b, float* out, int M, int d, hipStream_t st) {
+extern "C" int hriemo_rowdot_fwd(const void* Z, const float* Z32, const float* w, const float* b, float* out, int M, int d, hipStream_t st) {
   if (check_rows(M, d)) return 1;
-  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)Z, w, b, out, M, d);
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (const bf16_t*)Z, Z32, w, b, out, M, d);
   HRIEMO_LAUNCH_CHECK("rowdot_fwd_kernel");
   return 0;
 }
-extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* w, void* dZ, float* dw, float* db, int M, int d,
+extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db, int M, int d,
                                  hipStream_t st) {
   if (check_rows(M, d)) return 1;
-  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(256), 0, st, dl, (const bf16_t*)Z, w, (bf16_t*)dZ, dw, db, M, d);
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(256), 0, st, dl, (const bf16_t*)Z, Z32, w, (bf16_t*)dZ, dw, db, M, d);
   HRIEMO_LAUNCH_CHECK("rowdot_bwd_kernel");
   return 0;
 }
@@ -709,14 +728,14 @@ extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* w,
 // ---- beta gate ----
 extern "C" int hriemo_pool_chunks(int L) { return (L + 31) / 32; }
 
-extern "C" int hriemo_ln_pool_fwd(const void* X, const unsigned char* mask, const float* gamma, const float* beta, void* Yn,
+extern "C" int hriemo_ln_pool_fwd(const void* X, const float* X32, const unsigned char* mask, const float* gamma, const float* beta, void* Yn,
                                   float* mean, float* rstd, float* partials, int B, int L, int Lkeep, int d, float eps,
                                   hipStream_t st) {
   if (check_rows(B * L, d)) return 1;
   HRIEMO_CHECK(Lkeep >= 0 && Lkeep <= L, "ln_pool_fwd: Lkeep=%d out of range (L=%d)", Lkeep, L);
   const int nc = (L + 31) / 32;
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((ln_pool_fwd_kernel<N>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps)
+#define CALL(N) hipLaunchKernelGGL((ln_pool_fwd_kernel<N>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, X32, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_fwd_kernel");
@@ -782,13 +801,13 @@ extern "C" int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, cons
 extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return ((long)B * ((L + 31) / 32) * 2 * d + 64L * 2 * d) * 4; }
 
 extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
-                                  const void* X, const float* gamma, const float* mean, const float* rstd, void* dX,
+                                  const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
                                   float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hipStream_t st) {
   if (check_rows(B * L, d)) return 1;
   HRIEMO_CHECK(workspace != nullptr && Lf <= L, "ln_pool_bwd: bad arguments");
   const int nc = (L + 31) / 32;
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), 2 * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
+#define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), 2 * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");

@@ -14,13 +14,18 @@ class BetaGate(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(d_model * 4, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, d_model))
         self._sh = _ops.Shadows()
 
-    def forward(self, h_a, h_t, mask_a=None, mask_t=None):
-        out_dtype = h_a.dtype
-        h_a, h_t = _ops.to_bf16(h_a), _ops.to_bf16(h_t)
-        B, La, _ = h_a.shape
-        Lt = h_t.shape[1]
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t):
+        """h_fusion comes back bf16 only: it is consumed as a GEMM operand (the decoder's memory)."""
+        B, La, _ = a.shape
+        Lt = t.shape[1]
         kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
-        h_fusion, beta = _ops.BetaGateFn.apply(h_a, h_t, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight,
+        return _ops.BetaGateFn.apply(a, a32, t, t32, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight,
                                      self.norm_t.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
                                      self.mlp[2].bias, self._sh, kpm_a, kpm_t)
+
+    def forward(self, h_a, h_t, mask_a=None, mask_t=None):
+        out_dtype = h_a.dtype
+        a, a32 = _ops.as_pair(h_a)
+        t, t32 = _ops.as_pair(h_t)
+        h_fusion, beta = self._fwd_pair(a, a32, t, t32, mask_a, mask_t)
         return h_fusion.to(out_dtype), beta

@@ -3,7 +3,10 @@ CrossModalTransformer :130-166): same constructor arguments, forward signature, 
 state_dict keys; the arithmetic runs in the gfx950 kernels of libhriemo.so.
 
 The torch.nn modules created here (MultiheadAttention, LayerNorm, Linear) are PARAMETER CONTAINERS only
--- identical key names and default initialisation as the reference, their forward() is never called."""
+-- identical key names and default initialisation as the reference, their forward() is never called.
+
+Internally every activation of the residual stream travels as a pair (bf16 copy for the GEMM operands,
+fp32 twin for the residual/LayerNorm path): see _ops.as_pair and DESIGN.md (precision)."""
 import torch
 import torch.nn as nn
 
@@ -31,40 +34,45 @@ class CrossModalBlock(nn.Module):
         self._site = [_ops.new_site_base() for _ in range(6)]
         self.batch_offset = 0          # global index of this shard's first utterance (data parallel)
 
-    def _self(self, x, mha, ln, kpm, p, seed, site, need_w):
-        return _ops.SelfAttnLN.apply(x, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
-                                     ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed, site,
+    def _self(self, x, x32, mha, ln, kpm, p, seed, site, need_w):
+        return _ops.SelfAttnLN.apply(x, x32, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                                     mha.out_proj.bias, ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed, site,
                                      self.batch_offset, need_w)
 
-    def _cross(self, xq, xkv, mha, ln, kpm, p, seed, site, need_w):
-        return _ops.CrossAttnLN.apply(xq, xkv, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+    def _cross(self, xq, xq32, xkv, mha, ln, kpm, p, seed, site, need_w):
+        return _ops.CrossAttnLN.apply(xq, xq32, xkv, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                                       mha.out_proj.bias, ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed,
                                       site, self.batch_offset, need_w)
 
-    def _ffn(self, x, ffn, ln, p, seed, site):
-        return _ops.FFNLN.apply(x, ffn[0].weight, ffn[0].bias, ffn[2].weight, ffn[2].bias, ln.weight, ln.bias,
+    def _ffn(self, x, x32, ffn, ln, p, seed, site):
+        return _ops.FFNLN.apply(x, x32, ffn[0].weight, ffn[0].bias, ffn[2].weight, ffn[2].bias, ln.weight, ln.bias,
                                 self._sh, p, 0.0, seed, site, self.batch_offset)
 
-    def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):
-        out_dtype = h_a.dtype          # outputs come back in the caller's dtype (bf16 inside)
-        h_a, h_t = _ops.to_bf16(h_a), _ops.to_bf16(h_t)
-        B, La, _ = h_a.shape
-        Lt = h_t.shape[1]
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
+        """(bf16, fp32-twin) pairs in and out; returns (a, a32, t, t32, maps|None)"""
+        B, La, _ = a.shape
+        Lt = t.shape[1]
         kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
         p = self.p if self.training else 0.0
         seed = _ops.next_seed(self.training and p > 0)
         s = self._site
-        need = bool(return_attention)
-        h_a_self, w_a = self._self(h_a, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)      # :74-81
-        h_t_self, w_t = self._self(h_t, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)      # :85-92
-        x, w_a2t = self._cross(h_a_self, h_t_self, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
-        h_a_cm = self._ffn(x, self.ffn_a, self.norm_a2, p, seed, s[3])                                       # :106
-        x, w_t2a = self._cross(h_t_self, h_a_self, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
-        h_t_cm = self._ffn(x, self.ffn_t, self.norm_t2, p, seed, s[5])                                       # :119
-        h_a_cm, h_t_cm = h_a_cm.to(out_dtype), h_t_cm.to(out_dtype)
+        a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
+        t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
+        x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
+        a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
+        x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
+        t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
+        maps = {"audio_self": w_a, "text_self": w_t, "audio_queries_text": w_a2t, "text_queries_audio": w_t2a} if need else None
+        return a_cm, a_cm32, t_cm, t_cm32, maps
+
+    def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):
+        out_dtype = h_a.dtype          # outputs come back in the caller's dtype
+        a, a32 = _ops.as_pair(h_a)
+        t, t32 = _ops.as_pair(h_t)
+        a, a32, t, t32, maps = self._fwd_pair(a, a32, t, t32, mask_a, mask_t, bool(return_attention))
+        h_a_cm, h_t_cm = _ops.from_pair(a, a32, out_dtype), _ops.from_pair(t, t32, out_dtype)
         if return_attention:
-            return h_a_cm, h_t_cm, {"audio_self": w_a, "text_self": w_t, "audio_queries_text": w_a2t,
-                                    "text_queries_audio": w_t2a}
+            return h_a_cm, h_t_cm, maps
         return h_a_cm, h_t_cm
 
 
@@ -73,14 +81,20 @@ class CrossModalTransformer(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([CrossModalBlock(d_model, n_heads, dropout) for _ in range(num_layers)])
 
-    def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
         all_layers_attn = []
         for layer in self.layers:
-            if return_attention:
-                h_a, h_t, maps = layer(h_a, h_t, mask_a, mask_t, return_attention=True)
+            a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+            if need:
                 all_layers_attn.append(maps)
-            else:
-                h_a, h_t = layer(h_a, h_t, mask_a, mask_t, return_attention=False)
+        return a, a32, t, t32, all_layers_attn
+
+    def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):
+        out_dtype = h_a.dtype
+        a, a32 = _ops.as_pair(h_a)
+        t, t32 = _ops.as_pair(h_t)
+        a, a32, t, t32, maps = self._fwd_pair(a, a32, t, t32, mask_a, mask_t, bool(return_attention))
+        h_a, h_t = _ops.from_pair(a, a32, out_dtype), _ops.from_pair(t, t32, out_dtype)
         if return_attention:
-            return h_a, h_t, all_layers_attn
+            return h_a, h_t, maps
         return h_a, h_t

@@ -25,23 +25,29 @@ class ExplainableDecoderLayer(nn.Module):
         self._site = [_ops.new_site_base() for _ in range(3)]
         self.batch_offset = 0
 
-    def forward(self, tgt, memory, memory_key_padding_mask=None, return_attention=False):
-        out_dtype = tgt.dtype
-        tgt, memory = _ops.to_bf16(tgt), _ops.to_bf16(memory)
+    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need):
         B, L, _ = memory.shape
         kpm = _ops.mask_u8(memory_key_padding_mask, B, L)
         p = self.p if self.training else 0.0
         seed = _ops.next_seed(self.training and p > 0)
         sa, ca, s = self.self_attn, self.cross_attn, self._site
-        tgt, _ = _ops.SelfAttnLN.apply(tgt, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
-                                       self.norm1.weight, self.norm1.bias, self._sh, self.nhead, None, p, seed, s[0],
-                                       self.batch_offset, False)                                          # :42-43
-        tgt, w = _ops.CrossAttnLN.apply(tgt, memory, ca.in_proj_weight, ca.in_proj_bias, ca.out_proj.weight,
-                                        ca.out_proj.bias, self.norm2.weight, self.norm2.bias, self._sh, self.nhead,
-                                        kpm, p, seed, s[1], self.batch_offset, bool(return_attention))   # :48-55
-        tgt = _ops.FFNLN.apply(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-                               self.norm3.weight, self.norm3.bias, self._sh, p, p, seed, s[2], self.batch_offset)  # :58-59
-        tgt = tgt.to(out_dtype)
+        tgt, tgt32, _ = _ops.SelfAttnLN.apply(tgt, tgt32, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
+                                              sa.out_proj.bias, self.norm1.weight, self.norm1.bias, self._sh,
+                                              self.nhead, None, p, seed, s[0], self.batch_offset, False)     # :42-43
+        tgt, tgt32, w = _ops.CrossAttnLN.apply(tgt, tgt32, memory, ca.in_proj_weight, ca.in_proj_bias,
+                                               ca.out_proj.weight, ca.out_proj.bias, self.norm2.weight,
+                                               self.norm2.bias, self._sh, self.nhead, kpm, p, seed, s[1],
+                                               self.batch_offset, need)                                       # :48-55
+        tgt, tgt32 = _ops.FFNLN.apply(tgt, tgt32, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                      self.linear2.bias, self.norm3.weight, self.norm3.bias, self._sh, p, p, seed,
+                                      s[2], self.batch_offset)                                                # :58-59
+        return tgt, tgt32, w
+
+    def forward(self, tgt, memory, memory_key_padding_mask=None, return_attention=False):
+        out_dtype = tgt.dtype
+        t16, t32 = _ops.as_pair(tgt)
+        t16, t32, w = self._fwd_pair(t16, t32, _ops.to_bf16(memory), memory_key_padding_mask, bool(return_attention))
+        tgt = _ops.from_pair(t16, t32, out_dtype)
         return (tgt, w) if return_attention else (tgt, None)
 
 
@@ -55,20 +61,24 @@ class EmotionDecoder(nn.Module):
                                      for _ in range(num_layers)])
         self.out_proj = nn.Linear(d_model, 1) if use_output_layer else None
 
-    def forward(self, memory, memory_key_padding_mask=None, return_attention=False):
-        out_dtype = memory.dtype
-        memory = _ops.to_bf16(memory)
-        B = memory.size(0)
+    def _fwd(self, memory16, memory_key_padding_mask, need, out_dtype):
+        B = memory16.size(0)
         out = _ops.ExpandFn.apply(self.emotion_queries, B)                                                # :127
+        # fp32 twin of the broadcast queries (residual operand of the first layer; gradient flows via `out`)
+        out32 = self.emotion_queries.detach().float().unsqueeze(0).expand(B, -1, -1).contiguous() if _ops.TWIN else None
         all_layers_attn = []
         for layer in self.layers:
-            out, attn_map = layer(out, memory, memory_key_padding_mask, return_attention)
-            if return_attention and attn_map is not None:
+            out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need)
+            if need and attn_map is not None:
                 all_layers_attn.append(attn_map)
         logits = None
         if self.out_proj is not None:
-            logits = _ops.RowDotFn.apply(out, self.out_proj.weight, self.out_proj.bias)                  # :155
-        z = out.to(out_dtype)
+            logits = _ops.RowDotFn.apply(out, out32, self.out_proj.weight, self.out_proj.bias)           # :155
+        z = _ops.from_pair(out, out32, out_dtype)
+        return z, logits, all_layers_attn
+
+    def forward(self, memory, memory_key_padding_mask=None, return_attention=False):
+        z, logits, maps = self._fwd(_ops.to_bf16(memory), memory_key_padding_mask, bool(return_attention), memory.dtype)
         if return_attention:
-            return z, logits, all_layers_attn
+            return z, logits, maps
         return z, logits

@@ -2,6 +2,7 @@
 import torch
 import torch.nn as nn
 
+from .. import _ops
 from .cross_modal_block_tacfn import CrossModalTransformer
 from .beta_gate_tacfn import BetaGate
 from .emotion_decoder import EmotionDecoder
@@ -53,18 +54,14 @@ class FusionWithEmotionDecoder(nn.Module):
     def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):
         h_a, h_t = self._ensure_3d(h_a), self._ensure_3d(h_t)
         out_dtype = h_a.dtype
-        # one cast at the boundary; everything between the sub-modules stays bf16 in HBM
-        h_a, h_t = h_a.to(torch.bfloat16), h_t.to(torch.bfloat16)
-        if return_attention:
-            h_a_tilde, h_t_tilde, encoder_attns = self.cross_modal(h_a, h_t, mask_a, mask_t, return_attention=True)
-        else:
-            h_a_tilde, h_t_tilde = self.cross_modal(h_a, h_t, mask_a, mask_t, return_attention=False)
-            encoder_attns = None
-        h_fusion, beta = self.beta_gate(h_a_tilde, h_t_tilde, mask_a, mask_t)
+        need = bool(return_attention)
+        # one cast at the boundary; between the sub-modules activations travel as (bf16, fp32-twin) pairs
+        a, a32 = _ops.as_pair(h_a)
+        t, t32 = _ops.as_pair(h_t)
+        a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+        h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)
         fused_mask = self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
+        z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype)
         if return_attention:
-            z, logits, decoder_attns = self.emotion_decoder(memory=h_fusion, memory_key_padding_mask=fused_mask,
-                                                            return_attention=True)
-            return logits, beta, z.to(out_dtype), {"encoder": encoder_attns, "decoder": decoder_attns}
-        z, logits = self.emotion_decoder(memory=h_fusion, memory_key_padding_mask=fused_mask, return_attention=False)
-        return logits, beta, z.to(out_dtype)
+            return logits, beta, z, {"encoder": encoder_attns, "decoder": decoder_attns}
+        return logits, beta, z

@@ -69,15 +69,18 @@ int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const un
                       hriemo_stream_t stream);
 
 /* ---- y = LayerNorm(x + dropout(g)), eps, affine (X may be NULL: plain LayerNorm of g).
+ * The residual stream has an optional fp32 twin: X32 (read instead of the bf16 X when non-NULL) and Y32
+ * (written next to the bf16 Y when non-NULL).  bf16 rounding of the LayerNorm outputs is ~85 % of the
+ * path's end-to-end error (scripts_dev/precision_study.py); GEMM operands stay bf16.
  * Replaces norm(h + self.dropout(sub(h))) (cross_modal_block_tacfn.py:81,92,105,106,118,119;
  * emotion_decoder.py:43,55,59).  bwd writes dX (residual branch), dG (sub-layer branch, dropout mask
  * applied) and the column sums dgamma, dbeta, dbias (= colsum dG, the producing Linear's bias grad);
  * accumulate=1 adds them into the destination (fused accumulation into existing .grad buffers). */
-int hriemo_add_ln_fwd(const void* G, const void* X, const float* gamma, const float* beta, void* Y, float* mean,
-                      float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+int hriemo_add_ln_fwd(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                      float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
                       const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);
 long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
-int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* gamma, const float* mean,
+int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
                       const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
                       int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
                       unsigned site, long row_offset, float* workspace, hriemo_stream_t stream);
@@ -91,16 +94,16 @@ int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hriemo_stream_t
 int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed,
                         const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
 int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
-int hriemo_rowdot_fwd(const void* Z, const float* w, const float* b, float* out, int M, int d,
+int hriemo_rowdot_fwd(const void* Z, const float* Z32, const float* w, const float* b, float* out, int M, int d,
                       hriemo_stream_t stream);                                     /* emotion_decoder.py:155 */
-int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* w, void* dZ, float* dw, float* db, int M, int d,
+int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db, int M, int d,
                       hriemo_stream_t stream);
 
 /* ---- beta gate (models/beta_gate_tacfn.py:68-118): LayerNorm + masked mean-pool (:6-24,79-84),
  * gate input [a,t,|a-t|,a*t] (:87-89), w = sigmoid(MLP), beta = mean(w) (:92-95), fuse over the first
  * L positions (:98-116).  partials buffers are [B, hriemo_pool_chunks(L), d] fp32. */
 int hriemo_pool_chunks(int L);
-int hriemo_ln_pool_fwd(const void* X, const unsigned char* mask, const float* gamma, const float* beta, void* Yn,
+int hriemo_ln_pool_fwd(const void* X, const float* X32, const unsigned char* mask, const float* gamma, const float* beta, void* Yn,
                        float* mean, float* rstd, float* partials, int B, int L, int Lkeep, int d, float eps,
                        hriemo_stream_t stream);
 int hriemo_gate_input(const float* partials_a, const float* partials_t, const unsigned char* mask_a,
@@ -116,7 +119,7 @@ int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, const float* t_
                           float* dt, int B, int d, hriemo_stream_t stream);
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
 int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
-                       const void* X, const float* gamma, const float* mean, const float* rstd, void* dX,
+                       const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
                        float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hriemo_stream_t stream);
 
 /* ---- per-kernel-class HIP-event timing on the launch stream (bench.py roofline leg) */

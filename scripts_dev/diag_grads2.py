@@ -26,4 +26,6 @@ for init in ["closed", "random"]:
     ha2, ht2 = g["h_a"].cuda().requires_grad_(True), g["h_t"].cuda().requires_grad_(True)
     l2, b2, z2 = m(ha2, ht2, g["mask_a"].cuda(), g["mask_t"].cuda()); O.train_step_loss(l2, b2, g["y"].cuda()).backward()
     mine = sorted(rel(p.grad, gref[n]) for n, p in m.named_parameters())
+    worst = sorted(((rel(p.grad, gref[n]), n) for n, p in m.named_parameters()), reverse=True)[:4]
+    print("      worst:", [(round(a, 3), b) for a, b in worst])
     print(f"{init:7s} {name:14s} fwd z: mine {rel(z2, z):.4f} autocast {rel(z3, z):.4f} | param-grad rel err median/max: mine {mine[len(mine)//2]:.4f}/{mine[-1]:.4f}  autocast-bf16 {ac[len(ac)//2]:.4f}/{ac[-1]:.4f} | g_h_a mine {rel(ha2.grad, gha):.4f} autocast {rel(ha.grad, gha):.4f}")

@@ -190,9 +190,15 @@ def test_add_ln_fwd_bwd(ops, M, d, p, resid):
     y_ref = torch.nn.functional.layer_norm(s, (d,), gam, bet, 1e-5)
     y_ref.backward(dY.float())
 
-    y, mean, rstd = ops.add_ln_fwd(G.cuda(), X.cuda() if resid else None, gamma.cuda(), beta.cuda(), p, seed, site, roff)
+    y, y32, mean, rstd = ops.add_ln_fwd(G.cuda(), X.cuda() if resid else None, gamma.cuda(), beta.cuda(), p, seed, site, roff,
+                                        want32=True)
     assert (y.float().cpu() - y_ref.detach()).abs().max() <= 2e-2      # bf16 output of O(1..4) values
+    assert (y32.cpu() - y_ref.detach()).abs().max() <= 1e-4            # fp32 twin of the same LayerNorm output
     assert (mean.cpu() - s.detach().mean(-1)).abs().max() <= 1e-5
+    if resid:                                                          # fp32 residual twin as the input
+        y2, y2_32, _, _ = ops.add_ln_fwd(G.cuda(), None, gamma.cuda(), beta.cuda(), p, seed, site, roff,
+                                         x32=X.float().cuda(), want32=True)
+        assert torch.equal(y2_32, y32) and torch.equal(y2, y)
     dx, dg, dgam, dbet, dbias = ops.add_ln_bwd(dY.cuda(), G.cuda(), X.cuda() if resid else None, gamma.cuda(), mean, rstd,
                                                p, seed, site, roff)
     assert (dg.float().cpu() - Gf.grad).abs().max() <= 2e-2 * max(1.0, Gf.grad.abs().max().item())
@@ -209,7 +215,7 @@ def test_rowdot_expand(ops):
     z = torch.randn(B, Ne, d, generator=g).bfloat16().cuda().requires_grad_(True)
     w = torch.nn.Parameter(torch.randn(1, d, generator=g).cuda())
     b = torch.nn.Parameter(torch.randn(1, generator=g).cuda())
-    out = ops.RowDotFn.apply(z, w, b)
+    out = ops.RowDotFn.apply(z, None, w, b)
     ref = (z.float() @ w.t()).squeeze(-1) + b
     assert (out - ref).abs().max() <= 1e-3 * max(1.0, ref.abs().max().item())
     dl = torch.randn(B, Ne, generator=g).cuda()
