@@ -163,11 +163,13 @@ def test_components_vs_golden(H):
     gate = O.closed_form_init_(H.BetaGate(128, 32)).cuda().eval()
     with torch.no_grad():
         hf, beta = gate(cu(gg["h_a"]), cu(gg["h_t"]), cu(gg["mask_a"]), cu(gg["mask_t"]))
-    close(hf, gg["h_fusion"], what="h_fusion"); close(beta, gg["beta"], what="beta")
+    # h_fusion is produced in bf16 (it is the decoder's GEMM operand): one bf16 ulp at |x| in [2,4) is 1.6e-2,
+    # so the stand-alone gate output is held to the north-star 1e-2 rather than the 5e-3 of the fp32-twin outputs
+    close(hf, gg["h_fusion"], 1e-2, what="h_fusion"); close(beta, gg["beta"], what="beta")
     gg = load_golden("gate_eval_equal_len_nomask")
     with torch.no_grad():
         hf, beta = gate(cu(gg["h_a"]), cu(gg["h_t"]))
-    close(hf, gg["h_fusion"], what="h_fusion eq"); close(beta, gg["beta"], what="beta eq")
+    close(hf, gg["h_fusion"], 1e-2, what="h_fusion eq"); close(beta, gg["beta"], what="beta eq")
     gd = load_golden("decoder_eval_ragged")
     dec = O.closed_form_init_(H.EmotionDecoder(128, 5, 8, 2, 64, 0.1)).cuda().eval()
     with torch.no_grad():
