@@ -113,6 +113,26 @@ __device__ __forceinline__ void tile_commit(const TileRegs<HD, NR, NT>& t, char*
   }
 }
 
+// XCD-aware block -> (tile, batch*head) map.  Blocks are dealt round-robin over the 8 XCDs (private L2s), so
+// with the natural (tile fastest) order the tiles of one (batch, head) land on 8 different L2s and each
+// re-fetches that head's K/V (or Q/dO) through the fabric: 230-390 MB per launch measured (profiles/
+// r01_hbm_traffic.json).  Here blocks l, l+8, l+16, ... (one XCD) walk the tiles of the SAME (batch, head)
+// before moving on, so its operands are fetched once per XCD.  Placement only affects speed.
+__device__ __forceinline__ void tile_and_head(int ntiles, int nbh, int& tile, int& bh) {
+  const int l = blockIdx.x;
+  const int full = (nbh >> 3) << 3;                 // heads covered by complete groups of 8
+  const int lim = full * ntiles;
+  if (l < lim) {
+    const int r = l >> 3;
+    tile = r % ntiles;
+    bh = (r / ntiles) * 8 + (l & 7);
+  } else {                                          // remainder heads: natural order
+    const int r = l - lim;
+    tile = r % ntiles;
+    bh = full + r / ntiles;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int HD, int NW, int QW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
@@ -124,8 +144,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   float* mb = (float*)(lds + 2 * 64 * STRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int qbase = blockIdx.x * (NW * QW * 16) + wave * QW * 16;
+  int tile, bh;
+  tile_and_head((a.Lq + NW * QW * 16 - 1) / (NW * QW * 16), a.B * a.H, tile, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qbase = tile * (NW * QW * 16) + wave * QW * 16;
 
   bf16x8 qf[QW][KS];
 #pragma unroll
@@ -280,8 +302,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
   float* mb = (float*)(lds + 2 * 64 * STRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int qbase = blockIdx.x * (NW * QW * 16) + wave * QW * 16;
+  int tile, bh;
+  tile_and_head((a.Lq + NW * QW * 16 - 1) / (NW * QW * 16), a.B * a.H, tile, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int qbase = tile * (NW * QW * 16) + wave * QW * 16;
 
   bf16x8 qf[QW][KS], dof[QW][KS];
   float lse2[QW], dl[QW];
@@ -432,8 +456,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   float* del_s = lse_s + 32;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
-  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
-  const int kbase = blockIdx.x * (NW * KW * 16) + wave * KW * 16;
+  int tile, bh;
+  tile_and_head((a.Lk + NW * KW * 16 - 1) / (NW * KW * 16), a.B * a.H, tile, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int kbase = tile * (NW * KW * 16) + wave * KW * 16;
 
   bf16x8 kreg[KW][KS], vreg[KW][KS];
   bool kvalid[KW];
@@ -665,15 +691,15 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: unaligned O");
   hriemo_prof_begin(HP_ATTN_FWD, st);
   if (Lq > 64 && attn_wide(0)) {
-#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 2>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 2>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else if (Lq > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 1>), dim3((Lq + 63) / 64, B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 1>), dim3(((Lq + 63) / 64) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 1, 1>), dim3(1, B * H), dim3(64), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 1, 1>), dim3(B * H), dim3(64), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   }
@@ -702,15 +728,15 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
                    ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0, "attn_bwd: unaligned operand");
   hriemo_prof_begin(HP_ATTN_BWD_DQ, st);
   if (Lq > 64 && attn_wide(1)) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2>), dim3((Lq + 127) / 128, B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else if (Lq > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 1>), dim3((Lq + 63) / 64, B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 1>), dim3(((Lq + 63) / 64) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 1, 1>), dim3(1, B * H), dim3(64), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 1, 1>), dim3(B * H), dim3(64), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   }
@@ -718,15 +744,15 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   hriemo_prof_end(HP_ATTN_BWD_DQ, st, 6.0 * B * H * (double)Lq * Lk * head_dim);
   hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
   if (Lk > 64 && attn_wide(1)) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2>), dim3((Lk + 127) / 128, B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else if (Lk > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1>), dim3((Lk + 63) / 64, B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1>), dim3(1, B * H), dim3(64), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1>), dim3(B * H), dim3(64), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   }
