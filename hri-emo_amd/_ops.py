@@ -41,13 +41,41 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, slot=0):
-    """Caller-owned scratch for the C ABI (split-K slabs, column-sum partials); grows monotonically."""
-    key = (device.index, slot)
+    """Caller-owned scratch for the C ABI (split-K slabs, column-sum partials); grows monotonically.
+    One per (device, slot, stream): the audio and text branches may run on two streams concurrently."""
+    key = (device.index, slot, torch.cuda.current_stream(device).cuda_stream)
     t = _ws_cache.get(key)
     if t is None or t.numel() * 4 < nbytes:
         n = max(int(nbytes), 64 << 20) // 4 + 16
         t = torch.empty(n, dtype=torch.float32, device=device)
         _ws_cache[key] = t
+    return t
+
+
+_side_streams = {}
+TWO_STREAMS = _os_env_flag = None
+
+
+def side_stream(device):
+    """Second stream for the text branch of a CrossModalBlock (independent of the audio branch between the
+    joins); None when disabled (HRIEMO_TWO_STREAMS=0)."""
+    global TWO_STREAMS
+    if TWO_STREAMS is None:
+        import os
+        TWO_STREAMS = os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0"
+    if not TWO_STREAMS:
+        return None
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = s
+    return s
+
+
+def share(t, stream):
+    """tensor produced on another stream is about to be read on `stream`"""
+    if t is not None:
+        t.record_stream(stream)
     return t
 
 

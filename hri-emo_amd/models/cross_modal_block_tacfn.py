@@ -56,12 +56,40 @@ class CrossModalBlock(nn.Module):
         p = self.p if self.training else 0.0
         seed = _ops.next_seed(self.training and p > 0)
         s = self._site
-        a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
-        t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
-        x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
-        a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
-        x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
-        t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
+        _ops._require_gpu(a)
+        main = torch.cuda.current_stream(a.device)
+        side = _ops.side_stream(a.device)
+        if side is None:
+            a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
+            t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
+            x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
+            x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
+            t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
+        else:
+            # The audio and text branches only meet at the two cross-attentions (each reads the OTHER branch's
+            # self-attention output), so the text branch runs on a second stream: its small grids (B*T_t rows)
+            # fill the CUs the audio branch leaves idle.  Fork/join with stream waits; tensors that cross
+            # streams are recorded on the consumer stream (allocator safety); autograd replays the same streams
+            # in backward.
+            side.wait_stream(main)
+            for x_ in (t, t32, kpm_t, kpm_a):
+                _ops.share(x_, side)
+            with torch.cuda.stream(side):
+                t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
+            a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
+            main.wait_stream(side)
+            side.wait_stream(main)
+            _ops.share(t_s, main)
+            _ops.share(a_s, side)
+            with torch.cuda.stream(side):
+                x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)
+                t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])
+            x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])
+            main.wait_stream(side)
+            for x_ in (t_cm, t_cm32, w_t, w_t2a):
+                _ops.share(x_, main)
         maps = {"audio_self": w_a, "text_self": w_t, "audio_queries_text": w_a2t, "text_queries_audio": w_t2a} if need else None
         return a_cm, a_cm32, t_cm, t_cm32, maps
 
