@@ -9,6 +9,7 @@ from .models.cross_modal_block_tacfn import CrossModalBlock, CrossModalTransform
 from .models.beta_gate_tacfn import BetaGate  # noqa: F401
 from .models.emotion_decoder import EmotionDecoder, ExplainableDecoderLayer  # noqa: F401
 from .models.fusion_with_emotion_decoder import FusionWithEmotionDecoder  # noqa: F401
+from .models.mosei_fusion_with_emotion_decoder import MoseiFusionWithEmotionDecoder  # noqa: F401
 
 __all__ = ["CrossModalBlock", "CrossModalTransformer", "BetaGate", "EmotionDecoder", "ExplainableDecoderLayer",
-           "FusionWithEmotionDecoder"]
+           "FusionWithEmotionDecoder", "MoseiFusionWithEmotionDecoder"]

@@ -166,6 +166,21 @@ class GradSink:
                     hook(p)
 
 
+def padded_shadow(sh, p, kp):
+    """bf16 shadow of a [N,K] weight zero-padded to [N,kp] (kp = K rounded up to 8: 16-byte rows)"""
+    key = (id(p), "pad")
+    ent = sh._d.get(key)
+    ver = (p._version, p.data_ptr())
+    if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
+        _require_gpu(p)
+        s_ = ent[1] if ent is not None and ent[1].device == p.device else \
+            torch.zeros((p.shape[0], kp), dtype=BF16, device=p.device)
+        s_[:, :p.shape[1]].copy_(p.detach())
+        ent = (ver, s_)
+        sh._d[key] = ent
+    return ent[1]
+
+
 def to_bf16(x):
     return x if x.dtype == BF16 else x.to(BF16)
 
@@ -570,6 +585,38 @@ class BetaGateFn(torch.autograd.Function):
         _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
                   _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
         return dxa, None, dxt, None, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y[..., N] (fp32) = x[..., K] . W[N,K]^T + b for any K (MOSEI projections: K = 74 / 300, padded to a
+    multiple of 8 internally) -- models/mosei_fusion_with_emotion_decoder.py:41-42,63-65."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, sh):
+        _require_gpu(x)
+        K = x.shape[-1]
+        N = w.shape[0]
+        M = x.numel() // K
+        kp = (K + 7) // 8 * 8
+        xb = torch.zeros((M, kp), dtype=BF16, device=x.device)
+        xb[:, :K].copy_(x.reshape(M, K))
+        w16 = padded_shadow(sh, w, kp)
+        y = linear_fwd(xb, w16, b, out_f32=True)
+        ctx.save_for_backward(xb, w16)
+        ctx.cfg = (tuple(x.shape), x.dtype, K, N, M, kp)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w16 = ctx.saved_tensors
+        shape, xdtype, K, N, M, kp = ctx.cfg
+        dyb = dy.reshape(M, N).to(BF16).contiguous()
+        dx = linear_dx(dyb, w16)[:, :K].to(xdtype).reshape(shape) if ctx.needs_input_grad[0] else None
+        dwp = torch.empty((N, kp), dtype=torch.float32, device=dyb.device)
+        linear_dw(dyb, xb, dwp)
+        db = torch.empty(N, dtype=torch.float32, device=dyb.device)
+        colsum(dyb, db)
+        return dx, dwp[:, :K].contiguous(), db, None
 
 
 class ExpandFn(torch.autograd.Function):

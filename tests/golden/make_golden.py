@@ -26,6 +26,7 @@ from models.fusion_with_emotion_decoder import FusionWithEmotionDecoder  # noqa:
 from models.cross_modal_block_tacfn import CrossModalBlock  # noqa: E402  (reference)
 from models.beta_gate_tacfn import BetaGate  # noqa: E402  (reference)
 from models.emotion_decoder import EmotionDecoder  # noqa: E402  (reference)
+from models.mosei_fusion_with_emotion_decoder import MoseiFusionWithEmotionDecoder  # noqa: E402  (reference)
 
 torch.set_num_threads(4)
 
@@ -183,6 +184,28 @@ def component_cases():
         **{f"map.{i}": v for i, v in enumerate(maps)})
 
 
+def mosei_case():
+    """COVAREP d=74 / GloVe d=300 projections in front of the backbone (MOSEI defaults)."""
+    m = closed_form_init_(MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300)).eval()
+    g = torch.Generator().manual_seed(31)
+    B, Ta, Tt = 3, 50, 20
+    h_a, h_t = torch.randn(B, Ta, 74, generator=g), torch.randn(B, Tt, 300, generator=g)
+    la = torch.randint(Ta // 2, Ta + 1, (B,), generator=g)
+    lt = torch.randint(Tt // 2, Tt + 1, (B,), generator=g)
+    m_a, m_t = torch.arange(Ta)[None] >= la[:, None], torch.arange(Tt)[None] >= lt[:, None]
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+    mt = closed_form_init_(MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300, dropout=0.0)).train()
+    y = (torch.rand(B, 6, generator=g) < 0.3).float()
+    l2, b2, _ = mt(h_a, h_t, m_a, m_t)
+    loss = train_step_loss(l2, b2, y)
+    loss.backward()
+    npz("mosei_eval_train", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, logits=logits, beta=beta, z=z, y=y,
+        loss=loss.reshape(1), g_audio_proj_w=mt.audio_proj.weight.grad, g_audio_proj_b=mt.audio_proj.bias.grad,
+        g_text_proj_w=mt.text_proj.weight.grad, g_text_proj_b=mt.text_proj.bias.grad)
+
+
 if __name__ == "__main__":
     fusion_cases()
     component_cases()
+    mosei_case()

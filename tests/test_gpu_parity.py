@@ -326,3 +326,49 @@ def test_graph_captured_step_matches_eager_and_rccl_single_rank(H):
         assert torch.isfinite(l1) and torch.isfinite(l2) and not torch.equal(l1, l2)
     finally:
         dist.destroy_process_group()
+
+
+def test_mosei_wrapper_vs_golden_and_amp_gradscaler(H):
+    """SURVEY 8(f) rank 1+2: MoseiFusionWithEmotionDecoder (d_audio=74, d_text=300 -> odd-K projection GEMMs,
+    reference MOSEI defaults d_model=256 / 4 heads / hd=64) against the golden from the reference; and the
+    MOSEI trainer's AMP pattern (train_mosei_fusion_seq_level_decoder.py:380-402): autocast + GradScaler
+    scale/unscale/clip/step run unchanged on top of the custom autograd Functions."""
+    g = load_golden("mosei_eval_train")
+    ref = O.closed_form_init_(O.MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300))
+    m = H.MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300)
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m.cuda().eval()
+    args = (cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+    with torch.no_grad():
+        logits, beta, z = m(*args)
+        l4, b4, z4, pack = m(*args, return_attention=True)
+    close(logits, g["logits"], what="logits"); close(beta, g["beta"], what="beta"); close(z, g["z"], what="z")
+    assert len(pack["encoder"]) == 2 and pack["decoder"][0].shape == (3, 6, 20)
+    # gradients of the projections (dropout 0) vs the golden
+    mt = H.MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300, dropout=0.0)
+    mt.load_state_dict(ref.state_dict())
+    mt.cuda().train()
+    l2, b2, _ = mt(*args)
+    loss = O.train_step_loss(l2, b2, cu(g["y"]))
+    loss.backward()
+    close(loss.reshape(1), g["loss"], what="loss")
+    for name, key in (("audio_proj.weight", "g_audio_proj_w"), ("audio_proj.bias", "g_audio_proj_b"),
+                      ("text_proj.weight", "g_text_proj_w"), ("text_proj.bias", "g_text_proj_b")):
+        got = dict(mt.named_parameters())[name].grad
+        assert _rel(got, g[key]) <= 0.15, (name, _rel(got, g[key]))       # bf16 backward on the fixture weights
+    # AMP + GradScaler step
+    opt = torch.optim.AdamW(mt.parameters(), lr=1e-4)
+    scaler = torch.amp.GradScaler("cuda")
+    before = mt.audio_proj.weight.detach().clone()
+    opt.zero_grad(set_to_none=True)
+    with torch.amp.autocast("cuda"):
+        l3, b3, _ = mt(*args)
+        loss3 = O.train_step_loss(l3.float(), b3.float(), cu(g["y"]))
+    scaler.scale(loss3).backward()
+    scaler.unscale_(opt)
+    torch.nn.utils.clip_grad_norm_(mt.parameters(), 5.0)
+    scaler.step(opt)
+    scaler.update()
+    assert torch.isfinite(loss3) and not torch.equal(mt.audio_proj.weight.detach(), before)
+    close(loss3.reshape(1), g["loss"], what="amp loss")

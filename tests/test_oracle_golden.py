@@ -133,3 +133,17 @@ def test_block_gate_decoder_components():
     close(z, gd["z"]); close(logits, gd["logits"])
     for i, v in enumerate(maps):
         close(v, gd[f"map.{i}"])
+
+
+def test_mosei_wrapper():
+    g = load_golden("mosei_eval_train")
+    m = O.closed_form_init_(O.MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300)).eval()
+    with torch.no_grad():
+        logits, beta, z = m(g["h_a"], g["h_t"], g["mask_a"], g["mask_t"])
+    close(logits, g["logits"]); close(beta, g["beta"]); close(z, g["z"])
+    mt = O.closed_form_init_(O.MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300, dropout=0.0)).train()
+    l2, b2, _ = mt(g["h_a"], g["h_t"], g["mask_a"], g["mask_t"])
+    loss = O.train_step_loss(l2, b2, g["y"])
+    loss.backward()
+    close(loss.reshape(1), g["loss"])
+    close(mt.audio_proj.weight.grad, g["g_audio_proj_w"], 1e-4); close(mt.text_proj.bias.grad, g["g_text_proj_b"], 1e-4)
