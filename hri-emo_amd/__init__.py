@@ -10,6 +10,7 @@ from .models.beta_gate_tacfn import BetaGate  # noqa: F401
 from .models.emotion_decoder import EmotionDecoder, ExplainableDecoderLayer  # noqa: F401
 from .models.fusion_with_emotion_decoder import FusionWithEmotionDecoder  # noqa: F401
 from .models.mosei_fusion_with_emotion_decoder import MoseiFusionWithEmotionDecoder  # noqa: F401
+from .models.fusion_classifier import FusionClassifier  # noqa: F401
 
 __all__ = ["CrossModalBlock", "CrossModalTransformer", "BetaGate", "EmotionDecoder", "ExplainableDecoderLayer",
-           "FusionWithEmotionDecoder", "MoseiFusionWithEmotionDecoder"]
+           "FusionWithEmotionDecoder", "MoseiFusionWithEmotionDecoder", "FusionClassifier"]

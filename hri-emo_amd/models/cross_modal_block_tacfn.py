@@ -10,7 +10,10 @@ fp32 twin for the residual/LayerNorm path): see _ops.as_pair and DESIGN.md (prec
 import torch
 import torch.nn as nn
 
-from .. import _ops
+try:
+    from .. import _ops
+except ImportError:            # imported as top-level `models` (PYTHONPATH=<repo>/hri-emo_amd, the reference's import path)
+    from hri_emo_amd import _ops
 
 
 class CrossModalBlock(nn.Module):

@@ -5,7 +5,10 @@ the reference's MOSEI checkpoints load."""
 import torch
 import torch.nn as nn
 
-from .. import _ops
+try:
+    from .. import _ops
+except ImportError:            # imported as top-level `models` (PYTHONPATH=<repo>/hri-emo_amd, the reference's import path)
+    from hri_emo_amd import _ops
 from .fusion_with_emotion_decoder import FusionWithEmotionDecoder
 
 

@@ -205,7 +205,27 @@ def mosei_case():
         g_text_proj_w=mt.text_proj.weight.grad, g_text_proj_b=mt.text_proj.bias.grad)
 
 
+def legacy_cases():
+    """legacy cross-modal block (no self-attention) and FusionClassifier."""
+    from models.cross_modal_block import CrossModalTransformer as LegacyCMT   # reference
+    from models.fusion_classifier import FusionClassifier                      # reference
+    d, B = 128, 4
+    h_a, h_t, m_a, m_t = inputs(41, B, 24, 10, d, True)
+    leg = closed_form_init_(LegacyCMT(num_layers=2, d_model=d, n_heads=8, dropout=0.1)).eval()
+    with torch.no_grad():
+        oa, ot = leg(h_a, h_t, m_a, m_t)
+    clf = closed_form_init_(FusionClassifier(d_model=d, num_classes=4, n_heads=8, num_layers=2, beta_hidden=32)).eval()
+    with torch.no_grad():
+        logits, beta, pooled = clf(h_a, h_t, m_a, m_t)
+        g = torch.Generator().manual_seed(42)
+        xa, xt = torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+        l2, b2, p2 = clf(xa, xt)                                               # utterance-level [B, d] inputs
+    npz("legacy_eval", h_a=h_a, h_t=h_t, mask_a=m_a, mask_t=m_t, leg_a=oa, leg_t=ot, clf_logits=logits, clf_beta=beta,
+        clf_pooled=pooled, u_a=xa, u_t=xt, u_logits=l2, u_beta=b2, u_pooled=p2)
+
+
 if __name__ == "__main__":
     fusion_cases()
     component_cases()
     mosei_case()
+    legacy_cases()

@@ -372,3 +372,32 @@ def test_mosei_wrapper_vs_golden_and_amp_gradscaler(H):
     scaler.update()
     assert torch.isfinite(loss3) and not torch.equal(mt.audio_proj.weight.detach(), before)
     close(loss3.reshape(1), g["loss"], what="amp loss")
+
+
+def test_legacy_block_and_fusion_classifier_vs_golden(H):
+    """the legacy cross-modal block (what the reference's tests/test_cross_modal_block.py
+    runs) and FusionClassifier (tests/test_fusion_classifier.py), sequence- and utterance-level inputs."""
+    from hri_emo_amd.models.cross_modal_block import CrossModalTransformer as LegacyCMT
+    g = load_golden("legacy_eval")
+    ref = O.closed_form_init_(O.LegacyCrossModalTransformer(2, 128, 8, 0.1))
+    leg = LegacyCMT(num_layers=2, d_model=128, n_heads=8, dropout=0.1)
+    leg.load_state_dict(ref.state_dict(), strict=True)
+    leg.cuda().eval()
+    with torch.no_grad():
+        oa, ot = leg(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+    close(oa, g["leg_a"], what="legacy a"); close(ot, g["leg_t"], what="legacy t")
+    refc = O.closed_form_init_(O.FusionClassifier(128, 4, 8, 2, 32))
+    clf = H.FusionClassifier(d_model=128, num_classes=4, n_heads=8, num_layers=2, beta_hidden=32)
+    clf.load_state_dict(refc.state_dict(), strict=True)
+    clf.cuda().eval()
+    with torch.no_grad():
+        logits, beta, pooled = clf(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+        l2, b2, p2 = clf(cu(g["u_a"]), cu(g["u_t"]))
+    close(logits, g["clf_logits"], 1e-2, "clf logits"); close(beta, g["clf_beta"], what="clf beta")
+    close(pooled, g["clf_pooled"], 1e-2, "clf pooled")
+    close(l2, g["u_logits"], 1e-2, "utt logits"); close(p2, g["u_pooled"], 1e-2, "utt pooled")
+    # trains: gradients reach the head and the fusion blocks
+    clf.train()
+    out, _, _ = clf(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in clf.parameters())

@@ -147,3 +147,17 @@ def test_mosei_wrapper():
     loss.backward()
     close(loss.reshape(1), g["loss"])
     close(mt.audio_proj.weight.grad, g["g_audio_proj_w"], 1e-4); close(mt.text_proj.bias.grad, g["g_text_proj_b"], 1e-4)
+
+
+def test_legacy_block_and_fusion_classifier():
+    g = load_golden("legacy_eval")
+    leg = O.closed_form_init_(O.LegacyCrossModalTransformer(2, 128, 8, 0.1)).eval()
+    with torch.no_grad():
+        oa, ot = leg(g["h_a"], g["h_t"], g["mask_a"], g["mask_t"])
+    close(oa, g["leg_a"]); close(ot, g["leg_t"])
+    clf = O.closed_form_init_(O.FusionClassifier(128, 4, 8, 2, 32)).eval()
+    with torch.no_grad():
+        logits, beta, pooled = clf(g["h_a"], g["h_t"], g["mask_a"], g["mask_t"])
+        l2, b2, p2 = clf(g["u_a"], g["u_t"])
+    close(logits, g["clf_logits"]); close(beta, g["clf_beta"]); close(pooled, g["clf_pooled"])
+    close(l2, g["u_logits"]); close(p2, g["u_pooled"])
