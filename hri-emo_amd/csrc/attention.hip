@@ -247,13 +247,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[qs][dt] *= alpha;
       if (a.thr16 != 0) {
-        const uint32_t q = (uint32_t)(qbase + qs * 16 + i);
+        // keys 4g..4g+3 of each 16-key subtile = two hash pairs; one multiply-free step per extra pair
+        const uint32_t hb = drop_base(key32, (uint32_t)(qbase + qs * 16 + i), (uint32_t)((kt * 64 + 4 * g) >> 1));
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint32_t key = (uint32_t)(kt * 64 + n * 16 + 4 * g + r);
-            s[qs][n][r] = keep16(key32, q, key, a.thr16) ? s[qs][n][r] * a.inv_keep : 0.f;
+          for (int pr = 0; pr < 2; ++pr) {
+            const uint32_t x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
+            s[qs][n][2 * pr] = keep_lo(x, a.thr16) ? s[qs][n][2 * pr] * a.inv_keep : 0.f;
+            s[qs][n][2 * pr + 1] = keep_hi(x, a.thr16) ? s[qs][n][2 * pr + 1] * a.inv_keep : 0.f;
           }
       }
     }
@@ -398,19 +400,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
       }
 #pragma unroll
     for (int qs = 0; qs < QW; ++qs) {
-      const uint32_t q = (uint32_t)(qbase + qs * 16 + i);
+      const uint32_t hb = drop_base(key32, (uint32_t)(qbase + qs * 16 + i), (uint32_t)((kt * 64 + 4 * g) >> 1));
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = EXP2(s[qs][n][r] * sl2 + bias[r] - lse2[qs]);
-          float dpd = dp[qs][n][r];
-          if (a.thr16 != 0) {
-            const uint32_t key = (uint32_t)(kt * 64 + n * 16 + 4 * g + r);
-            dpd = keep16(key32, q, key, a.thr16) ? dpd * a.inv_keep : 0.f;
+        for (int pr = 0; pr < 2; ++pr) {
+          uint32_t x = 0xffffffffu;                       // dropout off: both halves >= any threshold
+          if (a.thr16 != 0) x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 2 * pr + e;
+            const float p = EXP2(s[qs][n][r] * sl2 + bias[r] - lse2[qs]);
+            float dpd = dp[qs][n][r];
+            if (a.thr16 != 0) dpd = (e ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16)) ? dpd * a.inv_keep : 0.f;
+            s[qs][n][r] = p * (dpd - dl[qs]);
           }
-          s[qs][n][r] = p * (dpd - dl[qs]);
         }
       }
     }
@@ -477,6 +482,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
       vreg[kw][ks] = (e < HD) ? *(const bf16x8*)(vp + e) : zero8();
     }
   }
+  uint32_t hkb[KW];                     // hash base of this lane's key: key32 + (key>>1)*CB  (a-term added per query)
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) hkb[kw] = 0u;
   f32x4 dk[KW][DT], dv[KW][DT];
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw)
@@ -487,6 +495,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
     }
   const float sl2 = a.scale * LOG2E;
   const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) hkb[kw] = drop_base(key32, 0u, (uint32_t)((kbase + kw * 16 + i) >> 1));
   const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
   const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
   const long lbase = ((long)b * a.H + h) * a.Lq;
@@ -551,8 +561,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
           float p = kvalid[kw] ? EXP2(s[kw][qs][r] * sl2 - lse4[r]) : 0.f;
           float pd = p, dpd = dp[kw][qs][r];
           if (a.thr16 != 0) {
-            const uint32_t q = (uint32_t)(qt * 32 + qs * 16 + 4 * g + r);
-            const bool keep = keep16(key32, q, key, a.thr16);
+            // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
+            const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * 32 + qs * 16 + 4 * g + r) * DROP_CA);
+            const bool keep = (key & 1u) ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16);
             pd = keep ? p * a.inv_keep : 0.f;
             dpd = keep ? dpd * a.inv_keep : 0.f;
           }

@@ -56,10 +56,31 @@ __host__ __device__ __forceinline__ uint32_t site_key(uint64_t seed, uint32_t si
   k = fmix32(k + (uint32_t)(seed >> 32) * 0x85ebca77u + site * 0x27d4eb2fu);
   return fmix32(k + c * 0x165667b1u);
 }
-// true = element is kept.  thr16 = round(p * 65536): P(drop) = thr16 / 65536.
+// Per-element uniforms.  One hash serves TWO adjacent elements of the minor index b (b = key position in
+// attention, column in the row kernels): x = mix24(key + a*CA + (b>>1)*CB); element b keeps the low 16 bits
+// if b is even, the high 16 bits if odd.  mix24 uses 24-bit multiplies (full-rate v_mul_u32_u24; the 32-bit
+// v_mul_lo_u32 of a murmur finaliser is quarter rate and made the hash the largest VALU cost of the
+// attention kernels).  Statistics (drop rate, neighbour correlations) match murmur3's finaliser:
+// scripts_dev/ rng study in DESIGN.md.  thr16 = round(p * 65536): P(drop) = thr16 / 65536.
+#define DROP_CA 0x9e3779b1u
+#define DROP_CB 0x85ebca77u
+__host__ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+  return (a & 0xffffffu) * (b & 0xffffffu);          // low 32 bits of the 24x24 product: one v_mul_u32_u24
+}
+__host__ __device__ __forceinline__ uint32_t mix24(uint32_t x) {
+  x ^= x >> 16; x = mul24(x, 0xB2AE35u); x ^= x >> 13; x = mul24(x, 0xEBCA6Bu); x ^= x >> 15;
+  return x;
+}
+// base for (a, pair index bp); further pairs of the same a are base + j*DROP_CB
+__host__ __device__ __forceinline__ uint32_t drop_base(uint32_t key, uint32_t a, uint32_t bp) {
+  return key + a * DROP_CA + bp * DROP_CB;
+}
+__host__ __device__ __forceinline__ bool keep_lo(uint32_t x, uint32_t thr16) { return (x & 0xffffu) >= thr16; }
+__host__ __device__ __forceinline__ bool keep_hi(uint32_t x, uint32_t thr16) { return (x >> 16) >= thr16; }
+// generic single-element form (true = element is kept)
 __host__ __device__ __forceinline__ bool keep16(uint32_t key, uint32_t a, uint32_t b, uint32_t thr16) {
-  uint32_t x = fmix32(key + a * 0x9e3779b1u + b * 0x85ebca77u);
-  return (x >> 16) >= thr16;
+  const uint32_t x = mix24(drop_base(key, a, b >> 1));
+  return (b & 1u) ? keep_hi(x, thr16) : keep_lo(x, thr16);
 }
 
 struct DropCfg {

@@ -41,6 +41,22 @@ __device__ __forceinline__ void block_colsum(float* lds_row, const float (&acc)[
   }
 }
 
+// keep flags of the 8 columns of chunk `ch` in row `row`: four hashes, two columns each
+__device__ __forceinline__ void row_keep8(uint32_t key32, uint32_t thr16, uint32_t row, int ch, bool (&kp)[8]) {
+  if (thr16 == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kp[j] = true;
+    return;
+  }
+  const uint32_t hb = drop_base(key32, row, (uint32_t)(ch * 4));
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    const uint32_t x = mix24(hb + (uint32_t)pr * DROP_CB);
+    kp[2 * pr] = keep_lo(x, thr16);
+    kp[2 * pr + 1] = keep_hi(x, thr16);
+  }
+}
+
 // residual operand: the fp32 twin of the stream when given, else its bf16 copy, else 0
 __device__ __forceinline__ void load_resid(const bf16_t* X, const float* X32, long off, float* xf) {
   if (X32 != nullptr) {
@@ -76,10 +92,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
         float gf[8], xf[8];
         bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
         load_resid(X, X32, row * d + ch * 8, xf);
+        bool kp8[8];
+        row_keep8(key32, dr.thr16, (uint32_t)(row_offset + row), ch, kp8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float gv = gf[j];
-          if (dr.thr16 != 0) gv = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? gv * dr.inv_keep : 0.f;
+          const float gv = kp8[j] ? gf[j] * dr.inv_keep : 0.f;
           s[c][j] = xf[j] + gv;
           sum += s[c][j];
         }
@@ -149,14 +166,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
         bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
         load_resid(X, X32, row * d + ch * 8, xf);
         bf8_to_f32(*(const bf16x8*)(dY + row * d + ch * 8), dyf);
+        row_keep8(key32, dr.thr16, (uint32_t)(row_offset + row), ch, kp[c]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float gv = gf[j];
-          kp[c][j] = true;
-          if (dr.thr16 != 0) {
-            kp[c][j] = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16);
-            gv = kp[c][j] ? gv * dr.inv_keep : 0.f;
-          }
+          const float gv = kp[c][j] ? gf[j] * dr.inv_keep : 0.f;
           const float sv = xf[j] + gv;
           xh[c][j] = (sv - mu) * rstd;
           dyg[c][j] = dyf[j] * gamma[ch * 8 + j];
@@ -178,7 +191,6 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
         for (int j = 0; j < 8; ++j) {
           ds[j] = rstd * (dyg[c][j] - c1 - xh[c][j] * c2);
           dg[j] = kp[c][j] ? ds[j] * dr.inv_keep : 0.f;
-          if (dr.thr16 == 0) dg[j] = ds[j];
           abias[c][j] += dg[j];
         }
         if (dX != nullptr) *(bf16x8*)(dX + row * d + ch * 8) = f32_to_bf8(ds);
@@ -282,9 +294,10 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict_
     const int ch = (int)(v - row * nch);
     float f[8];
     bf8_to_f32(*(const bf16x8*)(X + v * 8), f);
+    bool kp8[8];
+    row_keep8(key32, dr.thr16, (uint32_t)(row_offset + row), ch, kp8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      f[j] = keep16(key32, (uint32_t)(row_offset + row), (uint32_t)(ch * 8 + j), dr.thr16) ? f[j] * dr.inv_keep : 0.f;
+    for (int j = 0; j < 8; ++j) f[j] = kp8[j] ? f[j] * dr.inv_keep : 0.f;
     *(bf16x8*)(Y + v * 8) = f32_to_bf8(f);
   }
 }

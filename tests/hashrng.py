@@ -31,10 +31,24 @@ def thr16(p):
     return max(0, min(65535, t))
 
 
+def mix24(x):
+    """the kernels' per-element mixer (24-bit multiplies), see csrc/common.h"""
+    x = _u(x)
+    m24 = np.uint64(0xFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = ((x & m24) * np.uint64(0xB2AE35)) & M32
+    x ^= x >> np.uint64(13)
+    x = ((x & m24) * np.uint64(0xEBCA6B)) & M32
+    x ^= x >> np.uint64(15)
+    return x
+
+
 def keep(key32, a, b, p):
-    """boolean keep-mask for integer arrays a, b (broadcast)"""
-    x = fmix32((_u(key32) + ((_u(a) * np.uint64(0x9E3779B1)) & M32) + ((_u(b) * np.uint64(0x85EBCA77)) & M32)) & M32)
-    return (x >> np.uint64(16)) >= np.uint64(thr16(p))
+    """boolean keep-mask for integer arrays a, b (broadcast): one hash per PAIR of adjacent b, low/high 16 bits"""
+    b = _u(b)
+    x = mix24((_u(key32) + ((_u(a) * np.uint64(0x9E3779B1)) & M32) + (((b >> np.uint64(1)) * np.uint64(0x85EBCA77)) & M32)) & M32)
+    u16 = np.where((b & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    return u16 >= np.uint64(thr16(p))
 
 
 def inv_keep(p):
