@@ -53,123 +53,281 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* tile, int sub0, int ks
 }
 
 // ---- operand staging through buffer_load ... lds -------------------------------------------------
-// Per lane and wave-instruction the byte offset inside the block's operand window is CONSTANT over the
-// K loop; only the (wave-uniform) descriptor base advances by one K-step.  So the steady-state loop
-// spends no VALU on addresses.  Lanes outside the matrix carry offset 0x80000000 >= num_records, which
-// the hardware range check turns into zeros (no branches, no clamping).
+// Per lane and wave-instruction the byte offset inside a tile's operand window is the same for every tile
+// and K-step; only the (wave-uniform) descriptor base moves.  So the steady-state loop spends no VALU on
+// addresses.  Edge tiles and the ragged last K-step take a slower path that rebuilds the lane's row / column
+// and replaces out-of-matrix lanes by offset 0x80000000 >= num_records, which the hardware range check turns
+// into zeros (no branches around the loads, no clamping).
 #define OOB_OFF 0x80000000u
 
-template <int T, int ROWS, int PW>
-__device__ __forceinline__ void operand_offsets(unsigned (&off)[PW], long ld, int r0, int rmax, int wave, int lane) {
-#pragma unroll
-  for (int t = 0; t < PW; ++t) {
-    const int j = wave * PW + t;
-    if (T == 0) {
-      const int row = j * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ (row & 7);
-      off[t] = (r0 + row < rmax) ? (unsigned)((row * ld + c * 8) * 2) : OOB_OFF;
-    } else {
-      constexpr int CPR = ROWS / 8;        // 16-B chunks per k-row
-      constexpr int RPI = 64 / CPR;        // k-rows per wave-instruction
-      const int kr = j * RPI + lane / CPR;
-      const int key = (kr & 3) | (((kr >> 3) & 1) << 2);
-      const int c = (lane % CPR) ^ (key << 1);
-      off[t] = (r0 + c * 8 < rmax) ? (unsigned)((kr * ld + c * 8) * 2) : OOB_OFF;
-    }
+// Lane-invariant part of the operand addressing.  Wave-instruction j of an operand covers
+//   K-contiguous (T == 0): rows 8j..8j+7, lane -> row 8j + lane/8, 16-B chunk (lane&7) ^ (row&7); row&7 does not
+//     depend on j, so ONE per-lane byte offset serves every j and the j-dependent part is a scalar (soffset);
+//   K-strided (T == 1): k-rows RPI*j .. +RPI-1, lane -> k-row RPI*j + lane/CPR, chunk (lane%CPR) ^ (key(kr)<<1);
+//     key splits into a lane part (lane/CPR) and a wave-uniform part (from RPI*j), so two per-lane values plus
+//     one v_xor/v_add per instruction rebuild the offset.
+struct LaneOff { unsigned a, b; };
+
+template <int T, int ROWS>
+__device__ __forceinline__ LaneOff operand_lane(long ld, int lane) {
+  LaneOff lo;
+  if (T == 0) {
+    const int row = lane >> 3;
+    lo.a = (unsigned)((row * ld + ((lane & 7) ^ row) * 8) * 2);
+    lo.b = 0;
+  } else {
+    constexpr int CPR = ROWS / 8;        // 16-B chunks per k-row
+    const int lr = lane / CPR, lc = lane % CPR;
+    lo.a = (unsigned)(lr * ld * 2);
+    lo.b = (unsigned)((lc ^ (lr << 1)) << 4);
   }
+  return lo;
 }
 
-// krem = valid k extent of this K-step (>= 64 in the steady state)
+// valid = rows (T == 0) or columns (T == 1) of this tile that lie inside the matrix; krem = valid k extent of
+// this K-step (>= 64 in the steady state)
 template <int T, int ROWS, int PW>
-__device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, const unsigned (&off)[PW], int krem, int wave, int lane) {
+__device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, const LaneOff lo, long ld, int valid, int krem, int wave, int lane) {
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)OOB_OFF, 0x00020000);
+  const bool full = valid >= ROWS && krem >= 64;     // wave-uniform
+  constexpr int CPR = ROWS / 8;
+  constexpr int RPI = 64 / CPR;          // k-rows per wave-instruction (T == 1)
 #pragma unroll
   for (int t = 0; t < PW; ++t) {
     const int j = wave * PW + t;
-    unsigned o = off[t];
-    if (krem < 64) {                       // ragged last K-step only
-      if (T == 0) {
+    unsigned o;
+    int so;
+    if (T == 0) {
+      o = lo.a;
+      so = (int)(j * 16 * ld);
+      if (!full) {
         const int row = j * 8 + (lane >> 3);
         const int c = (lane & 7) ^ (row & 7);
-        if (c * 8 >= krem) o = OOB_OFF;
-      } else {
-        constexpr int CPR = ROWS / 8;
-        constexpr int RPI = 64 / CPR;
-        if (j * RPI + lane / CPR >= krem) o = OOB_OFF;
+        if (row >= valid || c * 8 >= krem) o = OOB_OFF;
+      }
+    } else {
+      const int kr0 = j * RPI;
+      const int ukey = (kr0 & 3) | (((kr0 >> 3) & 1) << 2);
+      const unsigned cb = lo.b ^ (unsigned)(ukey << 5);      // 16 * chunk
+      o = lo.a + cb;
+      so = (int)(kr0 * 2 * ld);
+      if (!full) {
+        if ((int)(cb >> 1) >= valid || kr0 + lane / CPR >= krem) o = OOB_OFF;
       }
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))(tile + j * 1024), 16, (int)o, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))(tile + j * 1024), 16, (int)o, so, 0, 0);
   }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int STAG>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
-  constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
+// One unit of work of a block: an output tile (and, for split-K, one K slice of it).
+struct TileInfo {
+  const bf16_t* abase;
+  const bf16_t* bbase;
+  int m0, n0, slice, a_valid, b_valid, kext, nk;
+};
+
+// ---- epilogue.  A lane owns C[m = .. + (lane&15)][n = .. + 4*(lane>>4) .. +3] of each 16x16 accumulator tile.
+// fp32 (weight gradients / split-K slabs): 16-byte stores straight from the accumulators.
+// bf16: bias / residual in fp32 registers, ReLU on the packed result, then each wave transposes 16 rows at a
+// time through its PRIVATE 2 KB of LDS (wave tiles are 64 columns = one 128-B line wide) so every global store
+// is 16 bytes of a full line.  No block barrier and no use of the operand ring: the next tile's operands are
+// already streaming into it.  The epilogue is instruction-bound (two waves per SIMD, ~MT*40 VALU/LDS ops each),
+// so the variant is a compile-time parameter, addresses are one per-lane offset + scalar offsets of a buffer
+// descriptor (edge lanes get an out-of-range offset: dropped stores / zero loads instead of branches), and all
+// aux loads of a tile are issued before its first store (vmcnt retires in order: a load behind a store would
+// wait for the store's acknowledgement).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4v;
+typedef __attribute__((ext_vector_type(8))) short s16x8v;
+
+template <int OUTF32, int EPI, int MT, int NTL>
+__device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs& p, const TileInfo& T, char* scratch,
+                                           int wm, int wn, int lane_in) {
+  static_assert(NTL == 4, "wave tiles are 64 columns wide");
+  // opaque copy: keeps every lane-derived address of the epilogue INSIDE the persistent tile loop; hoisted out
+  // of it (they are tile-invariant) they would sit in VGPRs across the main loop and push it into scratch
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  const int g = lane >> 4, i = lane & 15;
+  if (OUTF32) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int m = T.m0 + wm * MT * 16 + mi * 16 + i;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) {
+        const int n = T.n0 + wn * NTL * 16 + ni * 16 + 4 * g;
+        if (n >= p.N) continue;
+        f32x4 v = acc[mi][ni];
+        if (p.bias != nullptr && T.slice == 0) v += *(const f32x4*)(p.bias + n);
+        float* dst = p.splitk > 1 ? p.ws + ((long)T.slice * p.M + m) * p.N + n : (float*)p.C + (long)m * p.ldc + n;
+        if (p.splitk == 1 && p.accumulate) v += *(const f32x4*)dst;
+        *(f32x4*)dst = v;
+      }
+    }
+  } else {
+    const int mb = T.m0 + wm * MT * 16, nb = T.n0 + wn * 64;
+    const int rows_valid = p.M - mb, cols_valid = p.N - nb;          // may be <= 0 or beyond the wave tile
+    const bool full = rows_valid >= MT * 16 && cols_valid >= 64;     // wave-uniform
+    const int rr = lane >> 3, cc = lane & 7;                         // 16-byte line view: row rr (+8), chunk cc
+    char* cbase = (char*)((bf16_t*)p.C + (long)mb * p.ldc + nb);     // wave-uniform
+    const unsigned line_c = (unsigned)((rr * p.ldc + cc * 8) * 2);
+
+    f32x4 b4[NTL];
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni) {
+      const int n = nb + ni * 16 + 4 * g;
+      b4[ni] = (p.bias != nullptr && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // aux operands are fetched in chunks of CM row-blocks, one chunk ahead of the rows being stored, so a chunk's
+    // loads are always issued before the previous chunk's stores and at most two chunks sit in registers
+    constexpr int CM = MT >= 8 ? 2 : MT;
+    constexpr int NCH = MT / CM;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI >= 2 ? p.aux + (long)mb * p.ldaux + nb : (const bf16_t*)p.C), 0, (int)OOB_OFF, 0x00020000);
+    const unsigned frag_x = (unsigned)((i * p.ldaux + 4 * g) * 2);                                   // EPI 3: fragment view
+    const unsigned line_x = (cc * 8 < cols_valid) ? (unsigned)((rr * p.ldaux + cc * 8) * 2) : OOB_OFF;   // EPI 2: line view
+    u32x2 ax[2][EPI == 3 ? CM : 1][NTL];
+    u32x4 al[2][EPI == 2 ? CM : 1][2];
+    auto load_chunk = [&](int c, int buf) {
+#pragma unroll
+      for (int q = 0; q < CM; ++q) {
+        const int mi = c * CM + q;
+        if (EPI == 3) {       // + aux (residual), added in fp32 before the single rounding
+#pragma unroll
+          for (int ni = 0; ni < NTL; ++ni) {
+            const bool ok = full || (mi * 16 + i < rows_valid && ni * 16 + 4 * g < cols_valid);
+            ax[buf][q][ni] = __builtin_amdgcn_raw_buffer_load_b64(rx, ok ? (int)frag_x : (int)OOB_OFF, (int)((mi * 16 * p.ldaux + ni * 16) * 2), 0);
+          }
+        }
+        if (EPI == 2) {       // ReLU mask (aux > 0): commutes with the bf16 rounding, applied on the 16-byte lines
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const bool ok = full || mi * 16 + k * 8 + rr < rows_valid;
+            al[buf][q][k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (int)line_x : (int)OOB_OFF, (int)((mi * 16 + k * 8) * p.ldaux * 2), 0);
+          }
+        }
+      }
+    };
+    // per-lane LDS addresses: fragment writes (chunk (2ni + g/2) ^ (i&7)) and line reads (chunk cc ^ (row&7))
+    char* wr = scratch + i * 128 + (g & 1) * 8;
+    const int wsw = i & 7, gh = g >> 1;
+    const char* rd0 = scratch + rr * 128 + ((cc ^ rr) << 4);          // rows rr and rr+8 share row&7
+    if (EPI >= 2) load_chunk(0, 0);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (EPI >= 2 && c + 1 < NCH) load_chunk(c + 1, (c + 1) & 1);
+#pragma unroll
+      for (int q = 0; q < CM; ++q) {
+        const int mi = c * CM + q;
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni) {
+          f32x4 v = acc[mi][ni] + b4[ni];
+          if (EPI == 3) {
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[c & 1][q][ni]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)a4[e];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+          if (EPI == 1) {       // ReLU on the rounded values: max as int16 clears every negative (and -0)
+            const s16x4v z = {0, 0, 0, 0};
+            o = __builtin_bit_cast(bf16x4, __builtin_elementwise_max(__builtin_bit_cast(s16x4v, o), z));
+          }
+          *(LDS_PTR(bf16x4))(wr + (((ni * 2 + gh) ^ wsw) << 4)) = o;
+        }
+        // LDS stores hand their data over on a separate path and a later read of the same wave may overtake
+        // them: retire the stores first.  (The reads are retired before the next row-block's stores anyway:
+        // the global stores below consume them.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          u32x4 v = *(LDS_PTR(const u32x4))(rd0 + k * 1024);
+          if (EPI == 2) {
+            const s16x8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+            const s16x8v neg = __builtin_elementwise_sub_sat(z, __builtin_bit_cast(s16x8v, al[c & 1][q][k]));   // sign set <=> aux > 0
+            v &= __builtin_bit_cast(u32x4, neg >> 15);
+          }
+          const bool ok = mi * 16 + k * 8 + rr < rows_valid && cc * 8 < cols_valid;
+          // plain global store, uniform base + per-lane 32-bit offset.  (A raw-buffer store with the same
+          // offsets loses lanes on this path, nondeterministically, on 8-wave blocks; measured, not understood.)
+          if (full || ok) *(u32x4*)(cbase + (long)((mi * 16 + k * 8) * p.ldc * 2) + line_c) = v;
+        }
+      }
+    }
+  }
+}
+
+// Persistent kernel: the grid is one (or two) blocks per CU; block b belongs to XCD b & 7 and walks that XCD's
+// contiguous range of work units, so neighbouring tiles (same A row-panel) share an L2.  The operand ring is
+// one continuous stream over (tile, K-step): the first NS-1 stages of the NEXT tile are issued during the last
+// K-steps of the current one, the epilogue does not touch the ring and does not wait for its stores, so a
+// tile boundary costs neither a block launch, nor a cold prologue, nor a store drain.
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
+  constexpr int NWAVE = WM * WN;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 1024 / NWAVE, B_PW = B_BYTES / 1024 / NWAVE, LPT = A_PW + B_PW;
   constexpr int MT = BM / WM / 16, NTL = BN / WN / 16;
   static_assert(A_PW * NWAVE * 1024 == A_BYTES && B_PW * NWAVE * 1024 == B_BYTES, "tile must split evenly over waves");
-  static_assert(NS >= 2 && NS <= 4 && (NS - 1) * LPT < 64, "vmcnt range");
-  static_assert(OUTF32 || BM * BN * 2 <= NS * STAGE, "C staging must fit the operand ring");
+  static_assert(NS >= 2 && NS <= 3 && (NS - 1) * LPT < 64, "ring depth / vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay scalar
   const int wm = wave / WN, wn = wave % WN;
+  char* scratch = smem + NS * STAGE + wave * 2048;
 
-  // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (L2); give each XCD a
-  // contiguous range of tiles so neighbouring tiles (same A row-panel) hit the same L2.
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, qd = nwg >> 3, rm = nwg & 7;
-  const int wg = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+  // this block's work units: wg = beg + lb, beg + lb + nx, ... < end
+  // hardware places block b on XCD b % 8: an XCD with nx of the G blocks gets the matching share of the units
+  const int G = gridDim.x, nxcd = min(8, G), q = G / nxcd, r = G - q * nxcd;
+  const int xcd = blockIdx.x % nxcd, lb = blockIdx.x / nxcd, nx = q + (xcd < r ? 1 : 0);
+  const int before = xcd * q + min(xcd, r);            // blocks on lower-numbered XCDs
   const int tiles = p.tiles_m * p.tiles_n;
-  const int slice = wg / tiles;
-  const int t = wg - slice * tiles;
-  const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = slice * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg + 63) >> 6;
+  const long total = (long)tiles * p.splitk;
+  const int end = (int)(total * (before + nx) / G);
+  int wg = (int)(total * before / G) + lb;
+  if (wg >= end) return;
 
-  // block-local operand windows (offsets stay small whatever the tensor size)
-  const bf16_t* abase = TA == 0 ? p.A + (long)m0 * p.lda + kbeg : p.A + (long)kbeg * p.lda + m0;
-  const bf16_t* bbase = TB == 0 ? p.B + (long)n0 * p.ldb + kbeg : p.B + (long)kbeg * p.ldb + n0;
   const long astep = TA == 0 ? 64 : 64 * p.lda, bstep = TB == 0 ? 64 : 64 * p.ldb;
-  unsigned aoff[A_PW], boff[B_PW];
-  operand_offsets<TA, BM, A_PW>(aoff, p.lda, m0, p.M, wave, lane);
-  operand_offsets<TB, BN, B_PW>(boff, p.ldb, n0, p.N, wave, lane);
+  const LaneOff aoff = operand_lane<TA, BM>(p.lda, lane), boff = operand_lane<TB, BN>(p.ldb, lane);
 
-  auto stage = [&](int s, int kstep) {
-#if defined(HRIEMO_GEMM_ABL) && (HRIEMO_GEMM_ABL & 1)
-    if (kstep >= NS - 1) return;        // timing-only build: prologue stages only
-#endif
+  auto decode = [&](int w) {
+    TileInfo t;
+    t.slice = w / tiles;
+    const int r = w - t.slice * tiles;
+    const int tm = r / p.tiles_n, tn = r - tm * p.tiles_n;
+    t.m0 = tm * BM; t.n0 = tn * BN;
+    const int kbeg = t.slice * p.k_per_split;
+    t.kext = min(p.K, kbeg + p.k_per_split) - kbeg;
+    t.nk = (t.kext + 63) >> 6;
+    t.abase = TA == 0 ? p.A + (long)t.m0 * p.lda + kbeg : p.A + (long)kbeg * p.lda + t.m0;
+    t.bbase = TB == 0 ? p.B + (long)t.n0 * p.ldb + kbeg : p.B + (long)kbeg * p.ldb + t.n0;
+    t.a_valid = p.M - t.m0; t.b_valid = p.N - t.n0;
+    return t;
+  };
+  // The 128x64 wave tile runs at the 256-VGPR limit: there the per-lane offsets are rebuilt from the lane id at
+  // every K-step (a dozen VALU ops) instead of living in registers that the allocator would spill to scratch.
+  constexpr bool REBUILD = (MT * NTL > 16);
+  auto stage = [&](int s, const TileInfo& t, int kstep) {
     char* sa = smem + s * STAGE;
-    const int krem = kend - kbeg - kstep * 64;
-    stage_operand<TA, BM, A_PW>(sa, abase + kstep * astep, aoff, krem, wave, lane);
-    stage_operand<TB, BN, B_PW>(sa + A_BYTES, bbase + kstep * bstep, boff, krem, wave, lane);
+    const int krem = t.kext - kstep * 64;
+    if (REBUILD) {
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));        // opaque: keeps the rebuild inside the loop
+      const LaneOff ao = operand_lane<TA, BM>(p.lda, l2), bo = operand_lane<TB, BN>(p.ldb, l2);
+      stage_operand<TA, BM, A_PW>(sa, t.abase + kstep * astep, ao, p.lda, t.a_valid, krem, wave, lane);
+      stage_operand<TB, BN, B_PW>(sa + A_BYTES, t.bbase + kstep * bstep, bo, p.ldb, t.b_valid, krem, wave, lane);
+    } else {
+      stage_operand<TA, BM, A_PW>(sa, t.abase + kstep * astep, aoff, p.lda, t.a_valid, krem, wave, lane);
+      stage_operand<TB, BN, B_PW>(sa + A_BYTES, t.bbase + kstep * bstep, boff, p.ldb, t.b_valid, krem, wave, lane);
+    }
   };
 
   f32x4 acc[MT][NTL];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#if defined(HRIEMO_GEMM_ABL)
-  int abl_nfrag = 0;
-#endif
   auto load_frags = [&](const char* sa, int ks, bf16x8 (&af)[MT], bf16x8 (&bfr)[NTL]) {
-#if defined(HRIEMO_GEMM_ABL) && (HRIEMO_GEMM_ABL & 2)
-    if (abl_nfrag >= 2) {               // timing-only build: keep the first two fragment sets, keep them live
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) asm volatile("" : "+v"(af[mi]));
-#pragma unroll
-      for (int ni = 0; ni < NTL; ++ni) asm volatile("" : "+v"(bfr[ni]));
-      return;
-    }
-    ++abl_nfrag;
-#endif
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -189,192 +347,199 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const GemmArgs p) {
   };
   auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bfr)[NTL]) { mma_rows(af, bfr, 0, MT); };
 
-  // prologue: put NS-1 stages in flight, retire the first
+  // The host guarantees nk >= NS-1 for every work unit, so stream positions it+NS-1 of a tile fall either in
+  // the tile itself or in the first NS-1 stages of the next one.
+  TileInfo T = decode(wg);
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) stage(s, s);
-  if (nk > NS - 2) wait_vmcnt<(NS - 2) * LPT>(); else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-
-  bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
+  for (int s = 0; s < NS - 1; ++s) stage(s, T, s);
+  wait_vmcnt<(NS - 2) * LPT>();
   int cur = 0, nxt = NS - 1;          // ring slots of the stage being computed / being filled
-  if (STAG) {
-    // Staggered two-group schedule.  A SIMD hosts wave w (group 0) and wave w + NWAVE/2 (group 1).  Every
-    // K-step is split into an S-phase (LDS-DMA issue for stage it+NS-1, all fragment reads of stage it) and
-    // an M-phase (MFMAs only), each closed by a barrier; group 1 runs one phase behind, so on every SIMD one
-    // wave feeds the matrix pipe while its partner pays the DMA-issue / LDS-read time.  Needs NS >= 3:
-    // stage it is read at slots 2it (g0) / 2it+1 (g1); every wave confirms its share of stage it at the end
-    // of S(it-1) (counted vmcnt, then barrier), and the slot is only restaged in S(it+1), one barrier after
-    // the last group-1 read was retired (lgkmcnt(0) before the barrier).
-    static_assert(!STAG || NS >= 3, "stagger needs a 3-deep ring");
-    const bool g1 = wave >= NWAVE / 2;
-    if (g1) __builtin_amdgcn_s_barrier();
-    for (int it = 0; it < nk; ++it) {
-      if (it + NS - 1 < nk) stage(nxt, it + NS - 1);
-      load_frags(smem + cur * STAGE, 0, afA, bfA);
-      load_frags(smem + cur * STAGE, 1, afB, bfB);
-      if (it + NS - 1 < nk) wait_vmcnt<(NS - 2) * LPT>();
-      else wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      mma(afA, bfA);
-      mma(afB, bfB);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      cur = (cur + 1 == NS) ? 0 : cur + 1;
-      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-    }
-    if (!g1) __builtin_amdgcn_s_barrier();
-  } else {
-    // Software pipeline across the barrier: while the MFMAs of one 32-deep half-step run, the fragments of
-    // the next half-step are already being read (two register sets), and the retire-wait + barrier for
-    // stage it+1 sits in the MIDDLE of iteration it, so its first fragments load under the second cluster.
-    // Order inside an iteration (pinned with sched_barrier(0): hipcc otherwise moves the register-only MFMA
-    // clusters across the waits and the barrier, rule 18):
-    //   DMA(it+NS-1) | MFMA(A, rows 0..MT/2) | read B-set | MFMA(A, rest) | retire stage it+1 + barrier |
-    //   read next A-set | MFMA(B-set)
-    // so every fragment read has >= half a cluster of MFMAs to land, and the LDS-read retire before the
-    // barrier is a builtin s_waitcnt (lgkmcnt(0) only) the compiler can see, so it adds no wait of its own
-    // in front of the B cluster.
-    // fragment reads of the NEXT half-step are interleaved with the MFMAs of the current one in four
-    // equal groups (sched_group_barrier), so the LDS sees a steady trickle instead of 8 waves bursting
-    // 12 reads each right after the barrier.
-    constexpr int RD_A = (TA == 0 ? 1 : 2) * MT, RD_B = (TB == 0 ? 1 : 2) * NTL;     // ds_read instrs per set
-    auto interleave = [&]() {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        __builtin_amdgcn_sched_group_barrier(0x008, MT * NTL / 4, 0);               // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, (RD_A + RD_B + 3) / 4, 0);      // DS read
-      }
+
+  for (;;) {
+    const int nwg = wg + nx;
+    const bool has_next = nwg < end;
+    const int nk = T.nk;
+    // stream position it+NS-1: issue it if it exists; returns whether a stage group went out.  The next
+    // unit is decoded on the spot (scalar ALU, NS-1 times per tile) instead of living in SGPRs all loop long.
+    auto prefetch = [&](int it) -> bool {
+      const int ps = it + NS - 1;
+      if (ps < nk) { stage(nxt, T, ps); return true; }
+      if (has_next) { const TileInfo NX = decode(nwg); stage(nxt, NX, ps - nk); return true; }
+      return false;
     };
-    // 64x64 wave tiles have the registers for it (<= 16 accumulator tiles); the 128x64 wave tile of the
-    // 256x256 block is at the 256-VGPR limit and keeps the coarser split below.
-    constexpr bool ILV = (MT * NTL <= 16);
-    if (nk > 0) load_frags(smem, 0, afA, bfA);
-    for (int it = 0; it < nk; ++it) {
-      if (it + NS - 1 < nk) stage(nxt, it + NS - 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ILV) {
-        load_frags(smem + cur * STAGE, 1, afB, bfB);
-        mma(afA, bfA);
-        interleave();
-      } else {
-        __builtin_amdgcn_s_setprio(1);
-        mma_rows(afA, bfA, 0, MT / 2);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_frags(smem + cur * STAGE, 1, afB, bfB);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma_rows(afA, bfA, MT / 2, MT);
-        __builtin_amdgcn_s_setprio(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      cur = (cur + 1 == NS) ? 0 : cur + 1;
-      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      const bool more = it + 1 < nk;
-      if (more) {
-        // stage it+1 must have landed for every wave; our own reads of stage `it` must be retired before any
-        // wave may restage that slot (WAR).
-        if (it + NS - 1 < nk) wait_vmcnt<(NS - 2) * LPT>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone
-        __builtin_amdgcn_s_barrier();
-        if (ILV) {                                // reads + MFMAs in ONE scheduling region
+    __builtin_amdgcn_s_barrier();       // stage 0 of this tile (confirmed per wave before its last epilogue) is visible
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
+    {
+      // Software pipeline across the barrier: while the MFMAs of one 32-deep half-step run, the fragments of
+      // the next half-step are already being read (two register sets), and the retire-wait + barrier for
+      // stage it+1 sits in the MIDDLE of iteration it, so its first fragments load under the second cluster.
+      // Order inside an iteration (pinned with sched_barrier(0): hipcc otherwise moves the register-only MFMA
+      // clusters across the waits and the barrier, rule 18):
+      //   DMA(it+NS-1) | MFMA(A, rows 0..MT/2) | read B-set | MFMA(A, rest) | retire stage it+1 + barrier |
+      //   read next A-set | MFMA(B-set)
+      // so every fragment read has >= half a cluster of MFMAs to land, and the LDS-read retire before the
+      // barrier is a builtin s_waitcnt (lgkmcnt(0) only) the compiler can see, so it adds no wait of its own
+      // in front of the B cluster.
+      // fragment reads of the NEXT half-step are interleaved with the MFMAs of the current one in four
+      // equal groups (sched_group_barrier), so the LDS sees a steady trickle instead of 8 waves bursting
+      // 12 reads each right after the barrier.
+      constexpr int RD_A = (TA == 0 ? 1 : 2) * MT, RD_B = (TB == 0 ? 1 : 2) * NTL;     // ds_read instrs per set
+      auto interleave = [&]() {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NTL / 4, 0);               // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, (RD_A + RD_B + 3) / 4, 0);      // DS read
+        }
+      };
+      constexpr bool ILV = (MT * NTL <= 16);
+      constexpr bool HALF = !ILV && !OUTF32;
+      if constexpr (ILV) {
+        // 64x64 wave tiles: two full fragment sets, reads of the next half-step trickle between the MFMAs
+        load_frags(smem + cur * STAGE, 0, afA, bfA);
+        for (int it = 0; it < nk; ++it) {
+          const bool issued = prefetch(it);
           __builtin_amdgcn_sched_barrier(0);
-          load_frags(smem + cur * STAGE, 0, afA, bfA);
-          mma(afB, bfB);
+          load_frags(smem + cur * STAGE, 1, afB, bfB);
+          mma(afA, bfA);
           interleave();
           __builtin_amdgcn_sched_barrier(0);
-        } else {
-          load_frags(smem + cur * STAGE, 0, afA, bfA);
+          cur = (cur + 1 == NS) ? 0 : cur + 1;
+          nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+          if (it + 1 < nk) {
+            // stage it+1 must have landed for every wave; our own reads of stage `it` must be retired before
+            // any wave may restage that slot (WAR).
+            if (issued) wait_vmcnt<(NS - 2) * LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);        // reads + MFMAs in ONE scheduling region
+            load_frags(smem + cur * STAGE, 0, afA, bfA);
+            mma(afB, bfB);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(afB, bfB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if constexpr (!HALF) {
+        // 128x64 wave tile, fp32 output (weight gradients: both operands K-strided, twice the fragment reads, no
+        // aux epilogue): two full fragment sets, each 32-deep half-step = two clusters of 16 MFMAs.
+        //   DMA | MFMA(A, rows 0..MT/2) | read B-set | MFMA(A, rest) | retire stage it+1 + barrier |
+        //   read next A-set | MFMA(B-set)
+        load_frags(smem + cur * STAGE, 0, afA, bfA);
+        for (int it = 0; it < nk; ++it) {
+          const bool issued = prefetch(it);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+          mma_rows(afA, bfA, 0, MT / 2);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          load_frags(smem + cur * STAGE, 1, afB, bfB);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+          mma_rows(afA, bfA, MT / 2, MT);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = (cur + 1 == NS) ? 0 : cur + 1;
+          nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+          if (it + 1 < nk) {
+            if (issued) wait_vmcnt<(NS - 2) * LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            load_frags(smem + cur * STAGE, 0, afA, bfA);
+          } else {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_setprio(1);
+          mma(afB, bfB);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (ILV) {
+        // 128x64 wave tile (128 accumulator registers): the A fragments are double-buffered in HALVES (rows
+        // 0..63 / 64..127 of the wave tile) and B in two sets, 64 fragment registers instead of 96, so the loop
+        // stays clear of the 256-register limit.  Each 32-deep half-step is two clusters of 16 MFMAs; the reads
+        // for the cluster after next are issued right before a cluster and land underneath it:
+        //   L(a1,ks0) A(0) | L(a0,ks1) L(b',ks1) B(0) | L(a1,ks1) A(1) | retire + barrier |
+        //   L(a0,next) L(b,next) B(1)
+        constexpr int MH = MT / 2;
+        bf16x8 a0[MH], a1[MH], b0[NTL], b1[NTL];
+        auto load_a = [&](const char* sa, int ks, int half, bf16x8 (&af)[MH]) {
+#pragma unroll
+          for (int mi = 0; mi < MH; ++mi)
+            af[mi] = TA == 0 ? lds_row_frag(sa, wm * MT * 16 + (half * MH + mi) * 16, ks, lane)
+                             : lds_tr_frag<BM * 2>(sa, wm * MT * 16 + (half * MH + mi) * 16, ks, lane);
+        };
+        auto load_b = [&](const char* sa, int ks, bf16x8 (&bfr)[NTL]) {
+          const char* sb = sa + A_BYTES;
+#pragma unroll
+          for (int ni = 0; ni < NTL; ++ni)
+            bfr[ni] = TB == 0 ? lds_row_frag(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
+        };
+        auto cluster = [&](int half, const bf16x8 (&af)[MH], const bf16x8 (&bfr)[NTL]) {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int mi = 0; mi < MH; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NTL; ++ni)
+              acc[half * MH + mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[half * MH + mi][ni], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
-          mma(afB, bfB);
+        };
+        load_a(smem + cur * STAGE, 0, 0, a0);
+        load_b(smem + cur * STAGE, 0, b0);
+        for (int it = 0; it < nk; ++it) {
+          const bool issued = prefetch(it);
+          const char* sa = smem + cur * STAGE;
           __builtin_amdgcn_sched_barrier(0);
+          load_a(sa, 0, 1, a1);
+          cluster(0, a0, b0);
+          load_a(sa, 1, 0, a0);
+          load_b(sa, 1, b1);
+          cluster(1, a1, b0);
+          load_a(sa, 1, 1, a1);
+          cluster(0, a0, b1);
+          cur = (cur + 1 == NS) ? 0 : cur + 1;
+          nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+          if (it + 1 < nk) {
+            if (issued) wait_vmcnt<(NS - 2) * LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): a1 is in, slot released
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(smem + cur * STAGE, 0, 0, a0);
+            load_b(smem + cur * STAGE, 0, b0);
+          }
+          cluster(1, a1, b1);
         }
       }
-      if (!ILV) {                                 // big tile: one merged copy of the cluster (register budget)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(afB, bfB);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    // This wave's share of the next tile's stage 0 must have landed BEFORE its stores join the queue: loads
+    // complete in order among themselves, so a counted wait stays exact only while nothing but loads is older.
+    if (has_next) wait_vmcnt<(NS - 2) * LPT>();
+    if (OUTF32) {
+      store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
+    } else {
+      switch (p.epi) {        // wave-uniform; one specialised copy of the epilogue each
+        case 1: store_tile<0, 1, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        case 2: store_tile<0, 2, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        case 3: store_tile<0, 3, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        default: store_tile<0, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
       }
     }
-  }
-  __syncthreads();                    // everyone is done with the ring before it becomes the C staging area
-
-  // ---- epilogue.  A lane owns C[m = .. + (lane&15)][n = .. + 4*(lane>>4) .. +3] of each 16x16 tile.
-  const int g = lane >> 4, i = lane & 15;
-  if (OUTF32) {
-    // weight gradients / split-K slabs: 16-byte fp32 stores straight from the accumulators
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int m = m0 + wm * MT * 16 + mi * 16 + i;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int ni = 0; ni < NTL; ++ni) {
-        const int n = n0 + wn * NTL * 16 + ni * 16 + 4 * g;
-        if (n >= p.N) continue;
-        f32x4 v = acc[mi][ni];
-        if (p.bias != nullptr && slice == 0) v += *(const f32x4*)(p.bias + n);
-        float* dst = p.splitk > 1 ? p.ws + ((long)slice * p.M + m) * p.N + n : (float*)p.C + (long)m * p.ldc + n;
-        if (p.splitk == 1 && p.accumulate) v += *(const f32x4*)dst;
-        *(f32x4*)dst = v;
-      }
-    }
-  } else {
-    // bf16: bias / activation in registers, then through LDS (the operand ring is free after the last
-    // barrier) so every global store is 16 bytes of a full 128-B line instead of 8-B row fragments.
-    // Image: [BM][BN] bf16, 16-B chunk index ^= row & 15.
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int r = wm * MT * 16 + mi * 16 + i;
-      const int m = m0 + r;
-#pragma unroll
-      for (int ni = 0; ni < NTL; ++ni) {
-        const int cn = wn * NTL * 16 + ni * 16 + 4 * g;
-        const int n = n0 + cn;
-        f32x4 v = acc[mi][ni];
-        if (m < p.M && n < p.N) {
-          if (p.bias != nullptr) v += *(const f32x4*)(p.bias + n);
-          if (p.epi == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          } else if (p.epi == 3) {
-            const bf16x4 a4 = *(const bf16x4*)(p.aux + (long)m * p.ldaux + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)a4[e];
-          }   // epi == 2 (ReLU mask) commutes with the bf16 rounding: applied below on full 16-B lines
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
-        *(LDS_PTR(bf16x4))(smem + r * (BN * 2) + ((((cn >> 3) ^ (r & 15))) << 4) + ((cn >> 2) & 1) * 8) = o;
-      }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;
-#pragma unroll
-    for (int k = 0; k < BM * CPR / NTHR; ++k) {
-      const int id = tid + k * NTHR;
-      const int r = id / CPR, cc = id % CPR;
-      const int m = m0 + r, n = n0 + cc * 8;
-      if (m < p.M && n < p.N) {
-        bf16x8 v = *(LDS_PTR(const bf16x8))(smem + r * (BN * 2) + ((cc ^ (r & 15)) << 4));
-        if (p.epi == 2) {
-          const bf16x8 a8 = *(const bf16x8*)(p.aux + (long)m * p.ldaux + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ((float)a8[e] > 0.f) ? v[e] : (bf16_t)0.f;
-        }
-        *(bf16x8*)((bf16_t*)p.C + (long)m * p.ldc + n) = v;
-      }
-    }
+    if (!has_next) break;
+    T = decode(nwg);
+    wg = nwg;
   }
 }
 
@@ -394,34 +559,42 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------- host
-struct TileCfg { int bm, bn, threads, lds; };
+struct TileCfg { int bm, bn, threads, lds; };   // lds = bytes of the operand ring
 static const TileCfg kCfg[] = {
-    {128, 128, 256, 2 * 32768},   // 0: 128x128, 2x2 waves, 2 stages  (2 blocks/CU)
-    {128, 128, 256, 3 * 32768},   // 1: 128x128, 2x2 waves, 3 stages
-    {256, 128, 512, 3 * 49152},   // 2: 256x128, 4x2 waves, 3 stages
-    {256, 256, 512, 2 * 65536},   // 3: 256x256, 2x4 waves (128x64 per wave), 2 stages
-    {256, 128, 512, 2 * 49152},   // 4: 256x128, 4x2 waves, 2 stages
-    {128, 256, 512, 3 * 49152},   // 5: 128x256, 2x4 waves, 3 stages
-    {256, 128, 512, 3 * 49152},   // 6: 256x128, 4x2 waves, 3 stages, staggered S/M phases
-    {128, 256, 512, 3 * 49152},   // 7: 128x256, 2x4 waves, 3 stages, staggered S/M phases
-    {64, 128, 256, 2 * 24576},    // 8: 64x128, 2x2 waves (32x64 per wave), 2 stages: small-M problems
+    {128, 128, 256, 2 * 32768},   // 0: 128x128, 2x2 waves (64x64 per wave), 2 stages, two blocks per CU
+    {256, 128, 512, 3 * 49152},   // 1: 256x128, 4x2 waves (64x64 per wave), 3 stages
+    {256, 256, 512, 2 * 65536},   // 2: 256x256, 2x4 waves (128x64 per wave), 2 stages
+    {64, 128, 256, 2 * 24576},    // 3: 64x128, 2x2 waves (32x64 per wave), 2 stages: small-M problems
 };
 static const int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+static const int kCfgStages[] = {2, 3, 2, 2};
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
 static int g_force_cfg = -1;
 extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev/bench_gemm.py); -1 = heuristic
   g_force_cfg = (cfg >= 0 && cfg < kNumCfg) ? cfg : -1;
   return 0;
 }
 
-template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int STAG = 0>
-static void launch_one(const GemmArgs& a, int lds, hipStream_t st) {
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS>
+static void launch_one(const GemmArgs& a, int ring, hipStream_t st) {
+  const int lds = ring + WM * WN * 2048;          // operand ring + 2 KB epilogue scratch per wave
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  const int grid = a.tiles_m * a.tiles_n * a.splitk;
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, STAG>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  const long units = (long)a.tiles_m * a.tiles_n * a.splitk;
+  const long slots = (long)num_cus() * (lds <= 80 * 1024 ? 2 : 1);      // persistent: one block per resident slot
+  const int grid = (int)(units < slots ? units : slots);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
 }
 
 template <int TA, int TB, int OUTF32>
@@ -429,26 +602,21 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
   const int lds = kCfg[cfg].lds;
   switch (cfg) {
     case 0: launch_one<TA, TB, OUTF32, 128, 128, 2, 2, 2>(a, lds, st); break;
-    case 1: launch_one<TA, TB, OUTF32, 128, 128, 2, 2, 3>(a, lds, st); break;
-    case 2: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3>(a, lds, st); break;
-    case 3: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 2>(a, lds, st); break;
-    case 4: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 2>(a, lds, st); break;
-    case 5: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3>(a, lds, st); break;
-    case 6: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3, 1>(a, lds, st); break;
-    case 7: launch_one<TA, TB, OUTF32, 128, 256, 2, 4, 3, 1>(a, lds, st); break;
+    case 1: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3>(a, lds, st); break;
+    case 2: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 2>(a, lds, st); break;
     default: launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 2>(a, lds, st); break;
   }
 }
 
-// Tile choice from the measured sweep on MI355X (scripts_dev/bench_gemm.py, profiles/): the 256x256 tile
-// halves LDS-DMA issues and fragment reads per MFMA and wins whenever it still yields >= ~1 block per CU;
-// narrow outputs (N = d_model) keep the 128x128 tile at 2 blocks/CU.
+// Tile choice from the measured sweep on MI355X (scripts_dev/bench_gemm.py, profiles/r01_gemm_tile_sweep.log):
+// the 256x256 tile halves LDS-DMA issues and fragment reads per MFMA and wins when the output is wide enough
+// to give every CU several of them; narrower outputs take 256x128 (forward) or 128x128 at two blocks per CU.
 static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
-  if (ta == 1) return (M >= 512 && N >= 512 && (long)K >= 4096) ? 3 : 0;     // dW: split-K fills the chip
-  if (M < 1024 || N < 256) return (M <= 512 && N >= 256) ? 8 : 0;             // decoder / gate sized problems
-  if (tb == 0) return (N >= 2048 && M >= 16384) ? 3 : 7;                      // NT: 256x256, else staggered 128x256
-  return M >= 16384 ? 3 : 4;                                                  // NN
+  if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
+  if (M < 1024 || N < 256) return (M <= 512 && N >= 256) ? 3 : 0;               // decoder / gate sized problems
+  if (tb == 0) return (N >= 1536 && M >= 16384) ? 2 : 1;                       // NT
+  return (N >= 2048 && M >= 16384) ? 2 : 0;                                    // NN
 }
 
 extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
@@ -468,7 +636,7 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   HRIEMO_CHECK(c_is_f32 || !accumulate, "gemm: accumulate needs fp32 output");
 
   int cfg = pick_config(ta, tb, M, N, K);
-  if (cfg == 8 && ta == 1) cfg = 0;            // the 64-row tile has no K-strided A image (128-B rows cannot hold the swizzle)
+  if (cfg == 3 && ta == 1) cfg = 0;            // the 64-row tile has no K-strided A image (128-B rows cannot hold the swizzle)
   GemmArgs a;
   a.M = M; a.N = N; a.K = K;
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb;
@@ -479,8 +647,8 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   if (c_is_f32) {
     const long tiles = (long)a.tiles_m * a.tiles_n;
     const int ksteps = (K + 63) / 64;
-    const long slots = 256L * (kCfg[cfg].lds <= 65536 ? 2 : 1);
-    long want = (slots * 3 / 2 + tiles - 1) / tiles;   // ~1.5 rounds of resident blocks
+    const long slots = (long)num_cus() * (kCfg[cfg].lds + kCfg[cfg].threads * 32 <= 80 * 1024 ? 2 : 1);
+    long want = slots / tiles;                         // persistent grid: one work unit per resident block
     if (want > ksteps / 4) want = ksteps / 4;          // >= 4 K-steps (256 of K) per slice
     const long fit = workspace ? workspace_bytes / ((long)M * N * 4) : 0;
     if (want > fit) want = fit;
@@ -488,6 +656,11 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   }
   int kper = ((K + splitk - 1) / splitk + 63) / 64 * 64;
   splitk = (K + kper - 1) / kper;
+  if (kCfgStages[cfg] == 3 && K - (splitk - 1) * kper <= 64) {
+    // a 3-deep ring streams two K-steps ahead across work units: every unit needs >= 2 K-steps
+    cfg = 0;
+    a.tiles_m = (M + kCfg[cfg].bm - 1) / kCfg[cfg].bm; a.tiles_n = (N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
+  }
   a.splitk = splitk; a.k_per_split = kper;
 
   const int cls = ta ? HP_GEMM_TN : (tb ? HP_GEMM_NN : HP_GEMM_NT);

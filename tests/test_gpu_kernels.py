@@ -72,6 +72,34 @@ def test_gemm_tn_exact_splitk(ops, M, N, K):
     assert torch.equal(big[8:].cpu(), ref) and float(big[:8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_gemm_every_tile_config_and_persistent_walk(ops, cfg):
+    """Each tile configuration forced in turn: ragged edges, every epilogue, and a problem with more tiles than
+    resident blocks so the persistent walk (next-tile prefetch, private epilogue scratch) is exercised."""
+    from hri_emo_amd import _lib
+    L = _lib.lib()
+    L.hriemo_gemm_force_config(cfg)
+    try:
+        for (M, N, K) in [(200, 136, 96), (300, 264, 160), (8192, 4096, 128)]:
+            A, W, b = ints((M, K), seed=11), ints((N, K), seed=12), ints((N,), seed=13)
+            ref = A @ W.t() + b
+            y = ops.linear_fwd(A.cuda().bfloat16(), W.cuda().bfloat16(), b.cuda(), relu=True)
+            assert torch.equal(y.float().cpu(), ref.clamp(min=0).bfloat16().float()), (cfg, M, N, K, "nt relu")
+            dY, W2, aux = ints((M, N), seed=14), ints((N, K), seed=15), ints((M, K), seed=16)
+            ref2 = dY @ W2
+            dx2 = ops.linear_dx(dY.cuda().bfloat16(), W2.cuda().bfloat16(), epi=2, aux=aux.cuda().bfloat16())
+            assert torch.equal(dx2.float().cpu(), (ref2 * (aux > 0)).bfloat16().float()), (cfg, M, N, K, "nn mask")
+            dx3 = ops.linear_dx(dY.cuda().bfloat16(), W2.cuda().bfloat16(), epi=3, aux=aux.cuda().bfloat16())
+            assert torch.equal(dx3.float().cpu(), (ref2 + aux).bfloat16().float()), (cfg, M, N, K, "nn add")
+            X = ints((M, K), -2, 3, seed=17)
+            dYs = ints((M, N), -2, 3, seed=18)
+            out = torch.full((N, K), 1.0, dtype=torch.float32, device="cuda")
+            ops.linear_dw(dYs.cuda().bfloat16(), X.cuda().bfloat16(), out)
+            assert torch.equal(out.cpu(), dYs.t() @ X), (cfg, M, N, K, "tn")
+    finally:
+        L.hriemo_gemm_force_config(-1)
+
+
 def test_colsum_and_cast(ops):
     X = ints((1000, 264), seed=9)
     out = torch.empty(264, dtype=torch.float32, device="cuda")
