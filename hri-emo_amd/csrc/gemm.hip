@@ -32,10 +32,20 @@ struct GemmArgs {
   int accumulate;
 };
 
+// chunk swizzle of the 64-byte-row image (BK = 32): rows r..r+3 share one 256-B bank row, so the 16-B chunk c of
+// row r is stored at c ^ h((r>>2)&3), h = {0,2,3,1}: conflict-free for the ds_read_b128 lane groups
+__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <int BK>
 __device__ __forceinline__ bf16x8 lds_row_frag(const char* tile, int sub0, int ks, int lane) {
   const int row = sub0 + (lane & 15);
-  const int c = ks * 4 + (lane >> 4);
-  return *(LDS_PTR(const bf16x8))(tile + row * 128 + ((c ^ (row & 7)) << 4));
+  if (BK == 64) {
+    const int c = ks * 4 + (lane >> 4);
+    return *(LDS_PTR(const bf16x8))(tile + row * 128 + ((c ^ (row & 7)) << 4));
+  } else {
+    const int c = lane >> 4;
+    return *(LDS_PTR(const bf16x8))(tile + row * 64 + ((c ^ swz4(row)) << 4));
+  }
 }
 
 template <int ROWB>   // bytes per k-row of the strided image (256 or 512)
@@ -68,12 +78,31 @@ __device__ __forceinline__ bf16x8 lds_tr_frag(const char* tile, int sub0, int ks
 //     one v_xor/v_add per instruction rebuild the offset.
 struct LaneOff { unsigned a, b; };
 
-template <int T, int ROWS>
+// One LDS-DMA wave-instruction: 64 lanes x 16 bytes, global (descriptor + per-lane offset + scalar offset) ->
+// LDS at lds_addr + 16*lane.  Issued through inline asm on purpose: hipcc tracks the builtin form as an LDS store
+// that may alias every later ds_read and, once the K loop sits inside the persistent tile loop, puts
+// s_waitcnt vmcnt(0) between the DMA issue and the fragment reads of the same iteration, which serialises the
+// whole prefetch ring.  Hidden from the compiler, the ring is ordered by this file's own counted vmcnt waits and
+// barriers alone; waits the compiler computes for its own loads only become more conservative (the hidden
+// operations are younger than anything it waits for, and vmcnt retires in order).
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, __attribute__((ext_vector_type(4))) int rsrc, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+
+template <int T, int ROWS, int BK>
 __device__ __forceinline__ LaneOff operand_lane(long ld, int lane) {
   LaneOff lo;
   if (T == 0) {
-    const int row = lane >> 3;
-    lo.a = (unsigned)((row * ld + ((lane & 7) ^ row) * 8) * 2);
+    if (BK == 64) {
+      const int row = lane >> 3;
+      lo.a = (unsigned)((row * ld + ((lane & 7) ^ row) * 8) * 2);
+    } else {                             // 64-byte rows: 16 rows per instruction, chunk (lane&3) ^ swz4(row)
+      const int row = lane >> 2;
+      lo.a = (unsigned)((row * ld + ((lane & 3) ^ swz4(row)) * 8) * 2);
+    }
     lo.b = 0;
   } else {
     constexpr int CPR = ROWS / 8;        // 16-B chunks per k-row
@@ -85,13 +114,17 @@ __device__ __forceinline__ LaneOff operand_lane(long ld, int lane) {
 }
 
 // valid = rows (T == 0) or columns (T == 1) of this tile that lie inside the matrix; krem = valid k extent of
-// this K-step (>= 64 in the steady state)
-template <int T, int ROWS, int PW>
+// this K-step (>= BK in the steady state)
+template <int T, int ROWS, int PW, int BK>
 __device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, const LaneOff lo, long ld, int valid, int krem, int wave, int lane) {
-  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)OOB_OFF, 0x00020000);
-  const bool full = valid >= ROWS && krem >= 64;     // wave-uniform
+  // raw buffer descriptor {base[31:0], base[47:32] (stride 0), num_records, flags}, in SGPRs
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const unsigned long kb = (unsigned long)kbase;
+  const i32x4 rsrc = {(int)(unsigned)kb, (int)((kb >> 32) & 0xffffu), (int)OOB_OFF, 0x00020000};
+  const bool full = valid >= ROWS && krem >= BK;     // wave-uniform
   constexpr int CPR = ROWS / 8;
   constexpr int RPI = 64 / CPR;          // k-rows per wave-instruction (T == 1)
+  constexpr int RPJ = BK == 64 ? 8 : 16; // rows per wave-instruction (T == 0)
 #pragma unroll
   for (int t = 0; t < PW; ++t) {
     const int j = wave * PW + t;
@@ -99,10 +132,10 @@ __device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, c
     int so;
     if (T == 0) {
       o = lo.a;
-      so = (int)(j * 16 * ld);
+      so = (int)(j * RPJ * 2 * ld);
       if (!full) {
-        const int row = j * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
+        const int row = j * RPJ + (BK == 64 ? (lane >> 3) : (lane >> 2));
+        const int c = BK == 64 ? ((lane & 7) ^ (row & 7)) : ((lane & 3) ^ swz4(row));
         if (row >= valid || c * 8 >= krem) o = OOB_OFF;
       }
     } else {
@@ -115,7 +148,7 @@ __device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, c
         if ((int)(cb >> 1) >= valid || kr0 + lane / CPR >= krem) o = OOB_OFF;
       }
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))(tile + j * 1024), 16, (int)o, so, 0, 0);
+    lds_dma16((unsigned)(unsigned long)(LDS_PTR(char))(tile + j * 1024), rsrc, o, so);
   }
 }
 
@@ -230,9 +263,7 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)a4[e];
           }
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+          bf16x4 o = __builtin_convertvector(v, bf16x4);
           if (EPI == 1) {       // ReLU on the rounded values: max as int16 clears every negative (and -0)
             const s16x4v z = {0, 0, 0, 0};
             o = __builtin_bit_cast(bf16x4, __builtin_elementwise_max(__builtin_bit_cast(s16x4v, o), z));
@@ -243,13 +274,19 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
         // them: retire the stores first.  (The reads are retired before the next row-block's stores anyway:
         // the global stores below consume them.)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 ln[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ln[k] = *(LDS_PTR(const u32x4))(rd0 + k * 1024);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          u32x4 v = *(LDS_PTR(const u32x4))(rd0 + k * 1024);
+          u32x4 v = ln[k];
           if (EPI == 2) {
             const s16x8v z = {0, 0, 0, 0, 0, 0, 0, 0};
             const s16x8v neg = __builtin_elementwise_sub_sat(z, __builtin_bit_cast(s16x8v, al[c & 1][q][k]));   // sign set <=> aux > 0
             v &= __builtin_bit_cast(u32x4, neg >> 15);
+            // pin the masked line HERE: sunk into the predicated store below, the aux load would stay unretired on
+            // the not-taken path and hipcc would guard every fragment register of the K loop with s_waitcnt vmcnt
+            asm volatile("" : "+v"(v));
           }
           const bool ok = mi * 16 + k * 8 + rr < rows_valid && cc * 8 < cols_valid;
           // plain global store, uniform base + per-lane 32-bit offset.  (A raw-buffer store with the same
@@ -266,14 +303,16 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
 // one continuous stream over (tile, K-step): the first NS-1 stages of the NEXT tile are issued during the last
 // K-steps of the current one, the epilogue does not touch the ring and does not wait for its stores, so a
 // tile boundary costs neither a block launch, nor a cold prologue, nor a store drain.
-template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS>
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
   constexpr int NWAVE = WM * WN;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr bool STAG = (BK == 32);     // the 32-deep stage exists for the staggered two-group schedule only
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 1024 / NWAVE, B_PW = B_BYTES / 1024 / NWAVE, LPT = A_PW + B_PW;
   constexpr int MT = BM / WM / 16, NTL = BN / WN / 16;
   static_assert(A_PW * NWAVE * 1024 == A_BYTES && B_PW * NWAVE * 1024 == B_BYTES, "tile must split evenly over waves");
-  static_assert(NS >= 2 && NS <= 3 && (NS - 1) * LPT < 64, "ring depth / vmcnt range");
+  static_assert(NS >= 2 && NS <= 4 && (NS - 1) * LPT < 64, "ring depth / vmcnt range");
+  static_assert(!STAG || (NWAVE == 8 && NS == 4), "staggered schedule: 8 waves, 4 ring slots");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay scalar
@@ -291,8 +330,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
   int wg = (int)(total * before / G) + lb;
   if (wg >= end) return;
 
-  const long astep = TA == 0 ? 64 : 64 * p.lda, bstep = TB == 0 ? 64 : 64 * p.ldb;
-  const LaneOff aoff = operand_lane<TA, BM>(p.lda, lane), boff = operand_lane<TB, BN>(p.ldb, lane);
+  const long astep = TA == 0 ? BK : BK * p.lda, bstep = TB == 0 ? BK : BK * p.ldb;
+  const LaneOff aoff = operand_lane<TA, BM, BK>(p.lda, lane), boff = operand_lane<TB, BN, BK>(p.ldb, lane);
 
   auto decode = [&](int w) {
     TileInfo t;
@@ -302,7 +341,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
     t.m0 = tm * BM; t.n0 = tn * BN;
     const int kbeg = t.slice * p.k_per_split;
     t.kext = min(p.K, kbeg + p.k_per_split) - kbeg;
-    t.nk = (t.kext + 63) >> 6;
+    t.nk = (t.kext + BK - 1) / BK;
     t.abase = TA == 0 ? p.A + (long)t.m0 * p.lda + kbeg : p.A + (long)kbeg * p.lda + t.m0;
     t.bbase = TB == 0 ? p.B + (long)t.n0 * p.ldb + kbeg : p.B + (long)kbeg * p.ldb + t.n0;
     t.a_valid = p.M - t.m0; t.b_valid = p.N - t.n0;
@@ -313,16 +352,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
   constexpr bool REBUILD = (MT * NTL > 16);
   auto stage = [&](int s, const TileInfo& t, int kstep) {
     char* sa = smem + s * STAGE;
-    const int krem = t.kext - kstep * 64;
+    const int krem = t.kext - kstep * BK;
     if (REBUILD) {
       int l2 = lane;
       asm volatile("" : "+v"(l2));        // opaque: keeps the rebuild inside the loop
-      const LaneOff ao = operand_lane<TA, BM>(p.lda, l2), bo = operand_lane<TB, BN>(p.ldb, l2);
-      stage_operand<TA, BM, A_PW>(sa, t.abase + kstep * astep, ao, p.lda, t.a_valid, krem, wave, lane);
-      stage_operand<TB, BN, B_PW>(sa + A_BYTES, t.bbase + kstep * bstep, bo, p.ldb, t.b_valid, krem, wave, lane);
+      const LaneOff ao = operand_lane<TA, BM, BK>(p.lda, l2), bo = operand_lane<TB, BN, BK>(p.ldb, l2);
+      stage_operand<TA, BM, A_PW, BK>(sa, t.abase + kstep * astep, ao, p.lda, t.a_valid, krem, wave, lane);
+      stage_operand<TB, BN, B_PW, BK>(sa + A_BYTES, t.bbase + kstep * bstep, bo, p.ldb, t.b_valid, krem, wave, lane);
     } else {
-      stage_operand<TA, BM, A_PW>(sa, t.abase + kstep * astep, aoff, p.lda, t.a_valid, krem, wave, lane);
-      stage_operand<TB, BN, B_PW>(sa + A_BYTES, t.bbase + kstep * bstep, boff, p.ldb, t.b_valid, krem, wave, lane);
+      stage_operand<TA, BM, A_PW, BK>(sa, t.abase + kstep * astep, aoff, p.lda, t.a_valid, krem, wave, lane);
+      stage_operand<TB, BN, B_PW, BK>(sa + A_BYTES, t.bbase + kstep * bstep, boff, p.ldb, t.b_valid, krem, wave, lane);
     }
   };
 
@@ -331,10 +370,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
     const char* sb = sa + A_BYTES;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
-      af[mi] = TA == 0 ? lds_row_frag(sa, wm * MT * 16 + mi * 16, ks, lane) : lds_tr_frag<BM * 2>(sa, wm * MT * 16 + mi * 16, ks, lane);
+      af[mi] = TA == 0 ? lds_row_frag<BK>(sa, wm * MT * 16 + mi * 16, ks, lane) : lds_tr_frag<BM * 2>(sa, wm * MT * 16 + mi * 16, ks, lane);
 #pragma unroll
     for (int ni = 0; ni < NTL; ++ni)
-      bfr[ni] = TB == 0 ? lds_row_frag(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
+      bfr[ni] = TB == 0 ? lds_row_frag<BK>(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
   };
   auto mma_rows = [&](const bf16x8 (&af)[MT], const bf16x8 (&bfr)[NTL], int lo, int hi) {
 #pragma unroll
@@ -373,8 +412,44 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
 #pragma unroll
       for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // groups of LPT loads younger than stage it+1 when iteration `it` retires it
+    auto retire_next = [&](int it) {
+      const int young = has_next ? NS - 2 : min(NS - 2, max(0, nk - it - 2));
+      if (NS >= 4 && young >= 2) wait_vmcnt<(NS >= 4 ? 2 : 0) * LPT>();
+      else if (NS >= 3 && young >= 1) wait_vmcnt<(NS >= 3 ? 1 : 0) * LPT>();
+      else wait_vmcnt<0>();
+    };
+    if constexpr (STAG) {
+      // Staggered two-group schedule (256x256 tile, 32-deep stages).  A SIMD hosts wave w (group 0) and wave
+      // w + 4 (group 1).  Every K-step is an S-phase (LDS-DMA issue for stream position it+3, the 12 fragment
+      // reads of stage it, counted retire of stage it+1) and an M-phase (32 MFMAs), each closed by one barrier;
+      // group 1 runs one phase behind, so on every SIMD one wave feeds the matrix pipe while its partner pays
+      // the DMA-issue / LDS-read time (measured on the ingredient probe, scripts_dev/mfma_probe.hip: 1.85 of
+      // 2.0 PFLOP/s MFMA-only, against 1.49 for the same work with both waves in phase).
+      //   stage it is read in barrier slot 2it (g0) / 2it+1 (g1); every wave confirms its share of stage it at
+      //   the end of S(it-1), i.e. before either group reads it; ring slot (it+3)%4 == (it-1)%4 is restaged in
+      //   S(it), after the barrier that follows the last read of stage it-1 (slot 2it-1).
+      bf16x8 af[MT], bfr[NTL];
+      const bool g1 = wave >= NWAVE / 2;
+      if (g1) __builtin_amdgcn_s_barrier();
+      for (int it = 0; it < nk; ++it) {
+        prefetch(it);
+        load_frags(smem + cur * STAGE, 0, af, bfr);
+        retire_next(it);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): fragments in registers, slot released
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(af, bfr);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      }
+      if (!g1) __builtin_amdgcn_s_barrier();
+    } else {
     bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
-    {
       // Software pipeline across the barrier: while the MFMAs of one 32-deep half-step run, the fragments of
       // the next half-step are already being read (two register sets), and the retire-wait + barrier for
       // stage it+1 sits in the MIDDLE of iteration it, so its first fragments load under the second cluster.
@@ -477,14 +552,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         auto load_a = [&](const char* sa, int ks, int half, bf16x8 (&af)[MH]) {
 #pragma unroll
           for (int mi = 0; mi < MH; ++mi)
-            af[mi] = TA == 0 ? lds_row_frag(sa, wm * MT * 16 + (half * MH + mi) * 16, ks, lane)
+            af[mi] = TA == 0 ? lds_row_frag<BK>(sa, wm * MT * 16 + (half * MH + mi) * 16, ks, lane)
                              : lds_tr_frag<BM * 2>(sa, wm * MT * 16 + (half * MH + mi) * 16, ks, lane);
         };
         auto load_b = [&](const char* sa, int ks, bf16x8 (&bfr)[NTL]) {
           const char* sb = sa + A_BYTES;
 #pragma unroll
           for (int ni = 0; ni < NTL; ++ni)
-            bfr[ni] = TB == 0 ? lds_row_frag(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
+            bfr[ni] = TB == 0 ? lds_row_frag<BK>(sb, wn * NTL * 16 + ni * 16, ks, lane) : lds_tr_frag<BN * 2>(sb, wn * NTL * 16 + ni * 16, ks, lane);
         };
         auto cluster = [&](int half, const bf16x8 (&af)[MH], const bf16x8 (&bfr)[NTL]) {
           __builtin_amdgcn_s_setprio(1);
@@ -527,6 +602,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
     // This wave's share of the next tile's stage 0 must have landed BEFORE its stores join the queue: loads
     // complete in order among themselves, so a counted wait stays exact only while nothing but loads is older.
     if (has_next) wait_vmcnt<(NS - 2) * LPT>();
+#if defined(HRIEMO_GEMM_ABL) && (HRIEMO_GEMM_ABL & 8)
+    bool skip_epilogue;                 // timing-only build: no epilogue (stores only on an impossible value)
+    {
+      float sum = 0.f;
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTL; ++b) sum += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+      skip_epilogue = sum != 12345.678f;
+    }
+    if (skip_epilogue) {
+    } else
+#endif
     if (OUTF32) {
       store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
     } else {
@@ -559,15 +647,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------- host
-struct TileCfg { int bm, bn, threads, lds; };   // lds = bytes of the operand ring
+struct TileCfg { int bm, bn, threads, lds, ns, bk; };   // lds = bytes of the operand ring (ns stages of bk k)
 static const TileCfg kCfg[] = {
-    {128, 128, 256, 2 * 32768},   // 0: 128x128, 2x2 waves (64x64 per wave), 2 stages, two blocks per CU
-    {256, 128, 512, 3 * 49152},   // 1: 256x128, 4x2 waves (64x64 per wave), 3 stages
-    {256, 256, 512, 2 * 65536},   // 2: 256x256, 2x4 waves (128x64 per wave), 2 stages
-    {64, 128, 256, 2 * 24576},    // 3: 64x128, 2x2 waves (32x64 per wave), 2 stages: small-M problems
+    {128, 128, 256, 2 * 32768, 2, 64},   // 0: 128x128, 2x2 waves (64x64 per wave), 2 stages, two blocks per CU
+    {256, 128, 512, 3 * 49152, 3, 64},   // 1: 256x128, 4x2 waves (64x64 per wave), 3 stages
+    {256, 256, 512, 2 * 65536, 2, 64},   // 2: 256x256, 2x4 waves (128x64 per wave), 2 stages
+    {64, 128, 256, 2 * 24576, 2, 64},    // 3: 64x128, 2x2 waves (32x64 per wave), 2 stages: small-M problems
+    {256, 256, 512, 4 * 32768, 4, 32},   // 4: 256x256, 2x4 waves, 4 stages of 32 k, staggered two-group schedule
 };
 static const int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
-static const int kCfgStages[] = {2, 3, 2, 2};
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -583,18 +671,18 @@ extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev
   return 0;
 }
 
-template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS>
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK = 64>
 static void launch_one(const GemmArgs& a, int ring, hipStream_t st) {
   const int lds = ring + WM * WN * 2048;          // operand ring + 2 KB epilogue scratch per wave
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute((const void*)gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const long units = (long)a.tiles_m * a.tiles_n * a.splitk;
   const long slots = (long)num_cus() * (lds <= 80 * 1024 ? 2 : 1);      // persistent: one block per resident slot
   const int grid = (int)(units < slots ? units : slots);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, BK>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
 }
 
 template <int TA, int TB, int OUTF32>
@@ -604,6 +692,7 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     case 0: launch_one<TA, TB, OUTF32, 128, 128, 2, 2, 2>(a, lds, st); break;
     case 1: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3>(a, lds, st); break;
     case 2: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 2>(a, lds, st); break;
+    case 4: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 4, 32>(a, lds, st); break;
     default: launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 2>(a, lds, st); break;
   }
 }
@@ -616,7 +705,7 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
   if (M < 1024 || N < 256) return (M <= 512 && N >= 256) ? 3 : 0;               // decoder / gate sized problems
   if (tb == 0) return (N >= 1536 && M >= 16384) ? 2 : 1;                       // NT
-  return (N >= 2048 && M >= 16384) ? 2 : 0;                                    // NN
+  return (N >= 2048 && M >= 16384) ? 2 : 1;                                    // NN
 }
 
 extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
@@ -656,8 +745,8 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   }
   int kper = ((K + splitk - 1) / splitk + 63) / 64 * 64;
   splitk = (K + kper - 1) / kper;
-  if (kCfgStages[cfg] == 3 && K - (splitk - 1) * kper <= 64) {
-    // a 3-deep ring streams two K-steps ahead across work units: every unit needs >= 2 K-steps
+  if (K - (splitk - 1) * kper <= (kCfg[cfg].ns - 2) * kCfg[cfg].bk) {
+    // an NS-deep ring streams NS-1 K-steps ahead across work units: every unit needs >= NS-1 K-steps
     cfg = 0;
     a.tiles_m = (M + kCfg[cfg].bm - 1) / kCfg[cfg].bm; a.tiles_n = (N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   }

@@ -17,7 +17,7 @@ def timeit(fn, reps=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
 out = []
-for cfg in (0, 2):
+for cfg in (0, 1, 2, 4):
     L.hriemo_gemm_force_config(cfg)
     for (M, N, K) in [(25600, 3072, 768), (25600, 768, 3072), (25600, 768, 768), (25600, 2304, 768)]:
         A = torch.randn(M, K, device="cuda").bfloat16(); W = torch.randn(N, K, device="cuda").bfloat16(); b = torch.randn(N, device="cuda")
