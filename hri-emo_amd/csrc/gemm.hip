@@ -125,6 +125,20 @@ __device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, c
   constexpr int CPR = ROWS / 8;
   constexpr int RPI = 64 / CPR;          // k-rows per wave-instruction (T == 1)
   constexpr int RPJ = BK == 64 ? 8 : 16; // rows per wave-instruction (T == 0)
+  if (full) {                            // interior tile, full K-step: no per-lane work at all
+#pragma unroll
+    for (int t = 0; t < PW; ++t) {
+      const int j = wave * PW + t;
+      if (T == 0) {
+        lds_dma16((unsigned)(unsigned long)(LDS_PTR(char))(tile + j * 1024), rsrc, lo.a, (int)(j * RPJ * 2 * ld));
+      } else {
+        const int kr0 = j * RPI;
+        const int ukey = (kr0 & 3) | (((kr0 >> 3) & 1) << 2);
+        lds_dma16((unsigned)(unsigned long)(LDS_PTR(char))(tile + j * 1024), rsrc, lo.a + (lo.b ^ (unsigned)(ukey << 5)), (int)(kr0 * 2 * ld));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < PW; ++t) {
     const int j = wave * PW + t;
@@ -133,20 +147,16 @@ __device__ __forceinline__ void stage_operand(char* tile, const bf16_t* kbase, c
     if (T == 0) {
       o = lo.a;
       so = (int)(j * RPJ * 2 * ld);
-      if (!full) {
-        const int row = j * RPJ + (BK == 64 ? (lane >> 3) : (lane >> 2));
-        const int c = BK == 64 ? ((lane & 7) ^ (row & 7)) : ((lane & 3) ^ swz4(row));
-        if (row >= valid || c * 8 >= krem) o = OOB_OFF;
-      }
+      const int row = j * RPJ + (BK == 64 ? (lane >> 3) : (lane >> 2));
+      const int c = BK == 64 ? ((lane & 7) ^ (row & 7)) : ((lane & 3) ^ swz4(row));
+      if (row >= valid || c * 8 >= krem) o = OOB_OFF;
     } else {
       const int kr0 = j * RPI;
       const int ukey = (kr0 & 3) | (((kr0 >> 3) & 1) << 2);
       const unsigned cb = lo.b ^ (unsigned)(ukey << 5);      // 16 * chunk
       o = lo.a + cb;
       so = (int)(kr0 * 2 * ld);
-      if (!full) {
-        if ((int)(cb >> 1) >= valid || kr0 + lane / CPR >= krem) o = OOB_OFF;
-      }
+      if ((int)(cb >> 1) >= valid || kr0 + lane / CPR >= krem) o = OOB_OFF;
     }
     lds_dma16((unsigned)(unsigned long)(LDS_PTR(char))(tile + j * 1024), rsrc, o, so);
   }
@@ -306,13 +316,16 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
 template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
   constexpr int NWAVE = WM * WN;
-  constexpr bool STAG = (BK == 32);     // the 32-deep stage exists for the staggered two-group schedule only
+  // 32-deep stages: 8-wave blocks run the staggered two-group schedule; 4-wave blocks (two per CU, whose waves pair
+  // up on the SIMDs and drift apart on their own) the same K-step body without the second barrier
+  constexpr bool K32 = (BK == 32), STAG = K32 && (WM * WN == 8);
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 1024 / NWAVE, B_PW = B_BYTES / 1024 / NWAVE, LPT = A_PW + B_PW;
   constexpr int MT = BM / WM / 16, NTL = BN / WN / 16;
   static_assert(A_PW * NWAVE * 1024 == A_BYTES && B_PW * NWAVE * 1024 == B_BYTES, "tile must split evenly over waves");
   static_assert(NS >= 2 && NS <= 4 && (NS - 1) * LPT < 64, "ring depth / vmcnt range");
-  static_assert(!STAG || (NWAVE == 8 && NS == 4), "staggered schedule: 8 waves, 4 ring slots");
+  static_assert(!STAG || NS == 4, "staggered schedule: 4 ring slots");
+  static_assert(!K32 || NS >= 3, "32-deep stages need a ring of 3");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay scalar
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
       else if (NS >= 3 && young >= 1) wait_vmcnt<(NS >= 3 ? 1 : 0) * LPT>();
       else wait_vmcnt<0>();
     };
-    if constexpr (STAG) {
+    if constexpr (K32) {
       // Staggered two-group schedule (256x256 tile, 32-deep stages).  A SIMD hosts wave w (group 0) and wave
       // w + 4 (group 1).  Every K-step is an S-phase (LDS-DMA issue for stream position it+3, the 12 fragment
       // reads of stage it, counted retire of stage it+1) and an M-phase (32 MFMAs), each closed by one barrier;
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
       //   the end of S(it-1), i.e. before either group reads it; ring slot (it+3)%4 == (it-1)%4 is restaged in
       //   S(it), after the barrier that follows the last read of stage it-1 (slot 2it-1).
       bf16x8 af[MT], bfr[NTL];
-      const bool g1 = wave >= NWAVE / 2;
+      const bool g1 = STAG && wave >= NWAVE / 2;
       if (g1) __builtin_amdgcn_s_barrier();
       for (int it = 0; it < nk; ++it) {
         prefetch(it);
@@ -443,11 +456,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         mma(af, bfr);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (STAG) __builtin_amdgcn_s_barrier();
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
       }
-      if (!g1) __builtin_amdgcn_s_barrier();
+      if (STAG && !g1) __builtin_amdgcn_s_barrier();
     } else {
     bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
       // Software pipeline across the barrier: while the MFMAs of one 32-deep half-step run, the fragments of
@@ -704,7 +717,7 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
   if (M < 1024 || N < 256) return (M <= 512 && N >= 256) ? 3 : 0;               // decoder / gate sized problems
-  if (tb == 0) return (N >= 1536 && M >= 16384) ? 2 : 1;                       // NT
+  if (tb == 0) return (N >= 2048 && M >= 16384) ? 2 : 1;                       // NT
   return (N >= 2048 && M >= 16384) ? 2 : 1;                                    // NN
 }
 
