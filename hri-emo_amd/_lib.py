@@ -32,6 +32,9 @@ _SIGS = {
     "hriemo_gate_input": ("ppppiiiipppp" + "p", "i"),
     "hriemo_sigmoid_beta": ("pppiip", "i"),
     "hriemo_fuse_fwd": ("ppppiiip", "i"),
+    "hriemo_masked_mean_fwd": ("ppppiiip", "i"),
+    "hriemo_rowsum_f32": ("ppilp", "i"),
+    "hriemo_scalar_gate_dx": ("pipippppiiip", "i"),
     "hriemo_fuse_bwd_dw": ("ppppiiip", "i"),
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),
     "hriemo_gate_input_bwd": ("ppppppiip", "i"),

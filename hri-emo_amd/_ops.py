@@ -14,6 +14,7 @@ import itertools
 import math
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 
@@ -585,6 +586,71 @@ class BetaGateFn(torch.autograd.Function):
         _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
                   _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
         return dxa, None, dxt, None, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
+
+
+class LegacyBetaGateFn(torch.autograd.Function):
+    """(h_fusion, beta) of the legacy scalar gate, models/beta_gate.py:60-114: masked-mean pools of the raw features,
+    [a, t, |a-t|, a*t] -> Linear(4d,h) -> ReLU -> Linear(h,1) -> sigmoid = beta[B,1], h = beta*h_a[:, :L] + (1-beta)*h_t[:, :L].
+    Pooling, fusion and their backward run in the HIP kernels; the [B]-sized MLP is host-side plumbing (its local
+    graph is kept and differentiated in backward, so the big tensors see one fused gradient kernel each)."""
+
+    @staticmethod
+    def forward(ctx, h_a, h_t, w1, b1, w2, b2, kpm_a, kpm_t):
+        _require_gpu(h_a)
+        B, La, d = h_a.shape
+        Lt = h_t.shape[1]
+        L = La if La == Lt else Lt                      # beta_gate.py:97-101
+        if La < L:
+            raise RuntimeError(f"BetaGate: audio length {La} < text length {Lt}; the reference cannot fuse this either")
+        dev = h_a.device
+        xa, xt = _contig_bf16(h_a), _contig_bf16(h_t)
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _stream()
+        a_pool, t_pool = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
+        cnt_a, cnt_t = torch.empty(B, **f32), torch.empty(B, **f32)
+        _lib.call("hriemo_masked_mean_fwd", _p(xa), _p(kpm_a), _p(a_pool), _p(cnt_a), B, La, d, st)
+        _lib.call("hriemo_masked_mean_fwd", _p(xt), _p(kpm_t), _p(t_pool), _p(cnt_t), B, Lt, d, st)
+        with torch.enable_grad():
+            pa, pt = a_pool.detach().requires_grad_(True), t_pool.detach().requires_grad_(True)
+            params = [t.detach().requires_grad_(True) for t in (w1, b1, w2, b2)]
+            gin = torch.cat([pa, pt, (pa - pt).abs(), pa * pt], dim=-1)
+            beta = torch.sigmoid(F.linear(torch.relu(F.linear(gin, params[0], params[1])), params[2], params[3]))   # [B,1]
+        A = xa if La == L else xa[:, :L].contiguous()
+        T = xt
+        wfull = beta.detach().expand(B, d).contiguous()
+        H = torch.empty((B, L, d), dtype=BF16, device=dev)
+        _lib.call("hriemo_fuse_fwd", _p(wfull), _p(A), _p(T), _p(H), B, L, d, st)
+        ctx.save_for_backward(A, T, cnt_a, cnt_t, kpm_a, kpm_t)
+        ctx.local = (beta, pa, pt, params)
+        ctx.cfg = (B, La, Lt, L, d)
+        return H, beta.detach()
+
+    @staticmethod
+    def backward(ctx, dH, dbeta):
+        A, T, cnt_a, cnt_t, kpm_a, kpm_t = ctx.saved_tensors
+        beta, pa, pt, params = ctx.local
+        B, La, Lt, L, d = ctx.cfg
+        dev = A.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _stream()
+        L_ = _lib.lib()
+        dH2 = _contig_bf16(dH) if dH is not None else torch.zeros((B, L, d), dtype=BF16, device=dev)
+        nc = L_.hriemo_pool_chunks(L)
+        part = torch.empty((B, nc, d), **f32)
+        _lib.call("hriemo_fuse_bwd_dw", _p(dH2), _p(A), _p(T), _p(part), B, L, d, st)
+        dbeta_h = torch.empty(B, **f32)
+        _lib.call("hriemo_rowsum_f32", _p(part), _p(dbeta_h), B, nc * d, st)
+        g = dbeta_h.view(B, 1)
+        if dbeta is not None:
+            g = g + dbeta.float()
+        grads = torch.autograd.grad(beta, [pa, pt] + params, g)
+        dpa, dpt = grads[0].contiguous(), grads[1].contiguous()
+        bflat = beta.detach().reshape(B).contiguous()
+        dxa = torch.empty((B, La, d), dtype=BF16, device=dev)
+        dxt = torch.empty((B, Lt, d), dtype=BF16, device=dev)
+        _lib.call("hriemo_scalar_gate_dx", _p(dH2), L, _p(bflat), 1, _p(dpa), _p(cnt_a), _p(kpm_a), _p(dxa), B, La, d, st)
+        _lib.call("hriemo_scalar_gate_dx", _p(dH2), L, _p(bflat), 0, _p(dpt), _p(cnt_t), _p(kpm_t), _p(dxt), B, Lt, d, st)
+        return dxa, dxt, grads[2], grads[3], grads[4], grads[5], None, None
 
 
 class LinearFn(torch.autograd.Function):

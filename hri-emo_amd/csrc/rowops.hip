@@ -738,6 +738,78 @@ extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z3
   return 0;
 }
 
+// ------------------------------------------------------------------ legacy scalar beta gate (models/beta_gate.py)
+// pooled[b, :] = sum over valid rows of X[b, :, :] / max(#valid, 1)   (beta_gate.py:6-32); cnt[b] = max(#valid, 1)
+__global__ __launch_bounds__(256) void masked_mean_fwd_kernel(const bf16_t* __restrict__ X, const uint8_t* __restrict__ mask,
+                                                              float* __restrict__ pooled, float* __restrict__ cnt, int L, int d) {
+  __shared__ float red[4][64][8];
+  __shared__ float cred[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, ch = blockIdx.x * 64 + lane, nchunk = d >> 3;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float c = 0.f;
+  for (int l = wave; l < L; l += 4) {
+    const bool valid = mask == nullptr || mask[(long)b * L + l] == 0;
+    if (lane == 0 && valid) c += 1.f;
+    if (valid && ch < nchunk) {
+      const bf16x8 v = *(const bf16x8*)(X + ((long)b * L + l) * d + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wave][lane][j] = acc[j];
+  if (lane == 0) cred[wave] = c;
+  __syncthreads();
+  if (wave == 0) {
+    const float n = fmaxf(cred[0] + cred[1] + cred[2] + cred[3], 1.f);
+    if (ch < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        pooled[(long)b * d + ch * 8 + j] = (red[0][lane][j] + red[1][lane][j] + red[2][lane][j] + red[3][lane][j]) / n;
+    }
+    if (lane == 0 && blockIdx.x == 0) cnt[b] = n;
+  }
+}
+
+// out[b] = sum of the n floats of row b (dbeta of the scalar gate from the fuse_bwd_dw partials)
+__global__ __launch_bounds__(256) void rowsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long n) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) s += x[(long)b * n + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dX[b, l, :] = coef(b) * dH[b, l, :] (rows l < Lf) + valid(b, l) * dpool[b, :] / cnt[b],  coef = beta or 1 - beta
+// (backward of h_fusion = beta*h_a[:, :L] + (1-beta)*h_t[:, :L] and of masked_mean; beta_gate.py:97-112)
+__global__ void scalar_gate_dx_kernel(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ beta, int is_a,
+                                      const float* __restrict__ dpool, const float* __restrict__ cnt, const uint8_t* __restrict__ mask,
+                                      bf16_t* __restrict__ dX, int B, int L, int d) {
+  const int nch = d >> 3;
+  const long nv = (long)B * L * nch;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(v % nch);
+    const long row = v / nch;
+    const int b = (int)(row / L), l = (int)(row - (long)b * L);
+    const float coef = is_a ? beta[b] : 1.f - beta[b];
+    const bool valid = mask == nullptr || mask[row] == 0;
+    const float ic = valid ? 1.f / cnt[b] : 0.f;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ic * dpool[(long)b * d + ch * 8 + j];
+    if (l < Lf) {
+      const bf16x8 g = *(const bf16x8*)(dH + ((long)b * Lf + l) * d + ch * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += coef * (float)g[j];
+    }
+    *(bf16x8*)(dX + row * d + ch * 8) = f32_to_bf8(o);
+  }
+}
+
 // ---- beta gate ----
 extern "C" int hriemo_pool_chunks(int L) { return (L + 31) / 32; }
 
@@ -770,6 +842,37 @@ extern "C" int hriemo_sigmoid_beta(const float* pre, float* w, float* beta, int 
   HRIEMO_CHECK(B > 0 && d > 0, "sigmoid_beta: empty");
   hipLaunchKernelGGL(sigmoid_beta_kernel, dim3(B), dim3(256), 0, st, pre, w, beta, d);
   HRIEMO_LAUNCH_CHECK("sigmoid_beta_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_masked_mean_fwd(const void* X, const unsigned char* mask, float* pooled, float* cnt, int B, int L, int d,
+                                      hipStream_t st) {
+  if (check_rows(B * L, d)) return 1;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3((d / 8 + 63) / 64, B), dim3(256), 0, st, (const bf16_t*)X, mask, pooled, cnt, L, d);
+  HRIEMO_LAUNCH_CHECK("masked_mean_fwd_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, 1.0 * B * L * d * 2);
+  return 0;
+}
+
+extern "C" int hriemo_rowsum_f32(const float* x, float* out, int B, long n, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && n > 0, "rowsum_f32: empty problem");
+  hipLaunchKernelGGL(rowsum_f32_kernel, dim3(B), dim3(256), 0, st, x, out, n);
+  HRIEMO_LAUNCH_CHECK("rowsum_f32_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, const float* dpool, const float* cnt,
+                                     const unsigned char* mask, void* dX, int B, int L, int d, hipStream_t st) {
+  if (check_rows(B * L, d)) return 1;
+  HRIEMO_CHECK(Lf >= 0 && Lf <= L, "scalar_gate_dx: Lf=%d out of range (L=%d)", Lf, L);
+  long g = ((long)B * L * (d / 8) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(scalar_gate_dx_kernel, dim3((int)g), dim3(256), 0, st, (const bf16_t*)dH, Lf, beta, is_a, dpool, cnt, mask,
+                     (bf16_t*)dX, B, L, d);
+  HRIEMO_LAUNCH_CHECK("scalar_gate_dx_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, 2.0 * B * L * d * 2);
   return 0;
 }
 

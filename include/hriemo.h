@@ -117,6 +117,16 @@ int hriemo_gate_dpre(const float* partials, int L, const float* dbeta, const flo
                      hriemo_stream_t stream);
 int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, const float* t_pool, const float* cnt, float* da,
                           float* dt, int B, int d, hriemo_stream_t stream);
+/* Legacy scalar gate, models/beta_gate.py:6-32,60-114 (what the reference's tests/test_beta_gate.py exercises):
+ * masked mean pooling of the raw [B,L,d] features (pooled[B,d], cnt[B] = max(#valid,1)); the [B,4d]->h->1 MLP and
+ * its sigmoid are [B]-sized host-side plumbing; h_fusion = beta*h_a[:, :L] + (1-beta)*h_t[:, :L] reuses
+ * hriemo_fuse_fwd with beta broadcast over d, hriemo_fuse_bwd_dw + hriemo_rowsum_f32 give dbeta, and
+ * hriemo_scalar_gate_dx writes dX = coef*dH (first Lf rows) + valid*dpool/cnt in one pass. */
+int hriemo_masked_mean_fwd(const void* X, const unsigned char* mask, float* pooled, float* cnt, int B, int L, int d,
+                           hriemo_stream_t stream);
+int hriemo_rowsum_f32(const float* x, float* out, int B, long n, hriemo_stream_t stream);
+int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, const float* dpool, const float* cnt,
+                          const unsigned char* mask, void* dX, int B, int L, int d, hriemo_stream_t stream);
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
 int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                        const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,

@@ -224,8 +224,34 @@ def legacy_cases():
         clf_pooled=pooled, u_a=xa, u_t=xt, u_logits=l2, u_beta=b2, u_pooled=p2)
 
 
+def legacy_gate_case():
+    """the legacy scalar gate models/beta_gate.py (reference tests/test_beta_gate.py), sequence
+    inputs with ragged masks and unequal lengths (fusion length = text length) and the test's own [B,1,d] shape;
+    loss = sum(h_fusion * c) + 3 * sum(beta) with a fixed cotangent c, gradients w.r.t. inputs and MLP."""
+    from models.beta_gate import BetaGate as LegacyGate                       # reference
+    d, B = 128, 4
+    h_a, h_t, m_a, m_t = inputs(51, B, 24, 10, d, True)
+    gate = closed_form_init_(LegacyGate(d_model=d, hidden_dim=32))
+    g = torch.Generator().manual_seed(52)
+    c = torch.randn(B, 10, d, generator=g)
+    h_a.requires_grad_(True); h_t.requires_grad_(True)
+    hf, beta = gate(h_a, h_t, m_a, m_t)
+    ((hf * c).sum() + 3.0 * beta.sum()).backward()
+    xa, xt = torch.randn(B, 1, d, generator=g), torch.randn(B, 1, d, generator=g)
+    with torch.no_grad():
+        hu, bu = gate(xa, xt)
+    npz("legacy_gate", h_a=h_a.detach(), h_t=h_t.detach(), mask_a=m_a, mask_t=m_t, c=c, h_fusion=hf.detach(), beta=beta.detach(),
+        g_h_a=h_a.grad, g_h_t=h_t.grad, g_w1=gate.mlp[0].weight.grad, g_b1=gate.mlp[0].bias.grad,
+        g_w2=gate.mlp[2].weight.grad, g_b2=gate.mlp[2].bias.grad, u_a=xa, u_t=xt, u_h=hu, u_beta=bu)
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy_gate":      # add this fixture without rewriting the others
+        legacy_gate_case()
+        sys.exit(0)
     fusion_cases()
     component_cases()
     mosei_case()
     legacy_cases()
+    legacy_gate_case()

@@ -401,3 +401,24 @@ def test_legacy_block_and_fusion_classifier_vs_golden(H):
     out, _, _ = clf(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
     out.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in clf.parameters())
+
+
+def test_legacy_scalar_beta_gate_vs_golden(H):
+    """models/beta_gate.py (scalar gate, no LayerNorm) -- what the reference's tests/test_beta_gate.py
+    builds: ragged masks with unequal lengths, gradients w.r.t. inputs and the MLP, and the test's own [B,1,d] call."""
+    from hri_emo_amd.models.beta_gate import BetaGate as LegacyGate
+    g = load_golden("legacy_gate")
+    ref = O.closed_form_init_(O.LegacyBetaGate(128, 32))
+    gate = LegacyGate(d_model=128, hidden_dim=32)
+    gate.load_state_dict(ref.state_dict(), strict=True)
+    gate.cuda()
+    h_a, h_t = cu(g["h_a"]).requires_grad_(True), cu(g["h_t"]).requires_grad_(True)
+    hf, beta = gate(h_a, h_t, cu(g["mask_a"]), cu(g["mask_t"]))
+    close(hf, g["h_fusion"], 1e-2, "legacy gate h_fusion (bf16 output)"); close(beta, g["beta"], what="legacy gate beta")
+    ((hf * cu(g["c"])).sum() + 3.0 * beta.sum()).backward()
+    for got, key in [(h_a.grad, "g_h_a"), (h_t.grad, "g_h_t"), (gate.mlp[0].weight.grad, "g_w1"), (gate.mlp[0].bias.grad, "g_b1"),
+                     (gate.mlp[2].weight.grad, "g_w2"), (gate.mlp[2].bias.grad, "g_b2")]:
+        assert _rel(got, g[key]) < 2e-2, (key, _rel(got, g[key]))
+    with torch.no_grad():
+        hu, bu = gate(cu(g["u_a"]), cu(g["u_t"]))
+    close(hu, g["u_h"], 1e-2, "utterance-level h"); close(bu, g["u_beta"], what="utterance-level beta")

@@ -161,3 +161,18 @@ def test_legacy_block_and_fusion_classifier():
         l2, b2, p2 = clf(g["u_a"], g["u_t"])
     close(logits, g["clf_logits"]); close(beta, g["clf_beta"]); close(pooled, g["clf_pooled"])
     close(l2, g["u_logits"]); close(p2, g["u_pooled"])
+
+
+def test_legacy_scalar_beta_gate():
+    """models/beta_gate.py (legacy scalar gate): forward, and gradients w.r.t. inputs and MLP."""
+    g = load_golden("legacy_gate")
+    gate = O.closed_form_init_(O.LegacyBetaGate(128, 32))
+    h_a, h_t = g["h_a"].clone().requires_grad_(True), g["h_t"].clone().requires_grad_(True)
+    hf, beta = gate(h_a, h_t, g["mask_a"], g["mask_t"])
+    close(hf, g["h_fusion"]); close(beta, g["beta"])
+    ((hf * g["c"]).sum() + 3.0 * beta.sum()).backward()
+    close(h_a.grad, g["g_h_a"], 1e-4); close(h_t.grad, g["g_h_t"], 1e-4)
+    close(gate.mlp[0].weight.grad, g["g_w1"], 1e-4); close(gate.mlp[2].bias.grad, g["g_b2"], 1e-4)
+    with torch.no_grad():
+        hu, bu = gate(g["u_a"], g["u_t"])
+    close(hu, g["u_h"]); close(bu, g["u_beta"])
