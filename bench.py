@@ -145,6 +145,29 @@ def main():
     value = B * world / (ms * 1e-3)
     log(f"{ms:.3f} ms/step -> {value:.1f} utt/s (host enqueue {host_ms:.3f} ms/step)")
 
+    # optimizer step, timed separately: the trainer's clip_grad_norm_(5.0) + AdamW(lr 1e-4, wd 1e-2) on the
+    # fp32 parameters with the gradients of the last step (train_fusion_seq_level_decoder.py:332-334).  Never in `value`.
+    opt_ms = None
+    if rank == 0:
+        try:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2, fused=True)
+        except (TypeError, RuntimeError):
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+        snap = [p.detach().clone() for p in model.parameters()]
+        for i in range(6):
+            if i == 1:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+        torch.cuda.synchronize()
+        opt_ms = (time.perf_counter() - t1) / 5 * 1e3
+        with torch.no_grad():                       # leave the weights as they were for the legs below
+            for p, q in zip(model.parameters(), snap):
+                p.copy_(q)
+        del opt, snap
+        log(f"optimizer (clip 5.0 + AdamW) {opt_ms:.3f} ms/step, reported separately")
+
     roof = None
     if rank == 0 and not a.no_roofline:
         L = _lib.lib()
@@ -195,7 +218,7 @@ def main():
                           "grad_allreduce": "fp32 flat buckets 32MiB, RCCL" if world > 1 else "none",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "streams": 2 if os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0" else 1},
-               "host_enqueue_ms_per_step": round(host_ms, 3),
+               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3),
                "model_tflops": round(value * FLOP_PER_UTT_FWD_BWD / 1e12, 1),
                "model_mfma_frac": round(value * FLOP_PER_UTT_FWD_BWD / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
         if roof is not None:

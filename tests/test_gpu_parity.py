@@ -422,3 +422,30 @@ def test_legacy_scalar_beta_gate_vs_golden(H):
     with torch.no_grad():
         hu, bu = gate(cu(g["u_a"]), cu(g["u_t"]))
     close(hu, g["u_h"], 1e-2, "utterance-level h"); close(bu, g["u_beta"], what="utterance-level beta")
+
+
+def test_full_trainer_step_clip_adamw_vs_golden(H):
+    """The trainer's whole step on the golden inputs (train_fusion_seq_level_decoder.py:310-334): fwd -> loss ->
+    backward -> clip_grad_norm_(5.0) -> AdamW(lr 1e-4, wd 1e-2).step(): total gradient norm and the per-parameter
+    post-step deltas against the values recorded from the reference (harness row)."""
+    g = load_golden("cfg1_train_p0")
+    ref = O.closed_form_init_(O.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0))
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=1e-2)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    logits, beta, _ = m(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+    loss = O.train_step_loss(logits, beta, cu(g["y"]))
+    opt.zero_grad()
+    loss.backward()
+    tn = torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+    opt.step()
+    close(loss.reshape(1), g["loss"], what="loss")
+    assert abs(float(tn) - float(g["total_grad_norm"])) <= 2e-2 * float(g["total_grad_norm"]), (float(tn), float(g["total_grad_norm"]))
+    errs = []
+    for n, p in m.named_parameters():
+        dn, rn = float((p.detach() - before[n]).norm()), float(g["delta.norm." + n])
+        errs.append((abs(dn - rn) / max(rn, 1e-12), n))
+    errs.sort()
+    assert errs[len(errs) // 2][0] < 2e-2 and errs[len(errs) * 9 // 10][0] < 1e-1, errs[-4:]
