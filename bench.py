@@ -112,6 +112,8 @@ def main():
     model = H.FusionWithEmotionDecoder(**CFG).to(device).train()
     use_graph = not a.no_graph
     dp = DataParallelStep(model, fusion_step_loss, overlap=not use_graph)
+    from hri_emo_amd.optim import FusedClipAdamW
+    opt = FusedClipAdamW(dp.buckets, lr=1e-4, weight_decay=1e-2, max_norm=5.0)     # before capture: re-homes the parameters
     B = a.batch_per_gpu
     dp.set_global_batch(B * world)
     batch = synth(B, rank, device)
@@ -146,27 +148,21 @@ def main():
     log(f"{ms:.3f} ms/step -> {value:.1f} utt/s (host enqueue {host_ms:.3f} ms/step)")
 
     # optimizer step, timed separately: the trainer's clip_grad_norm_(5.0) + AdamW(lr 1e-4, wd 1e-2) on the
-    # fp32 parameters with the gradients of the last step (train_fusion_seq_level_decoder.py:332-334).  Never in `value`.
+    # flat fp32 parameter buffer with the gradients of the last step (train_fusion_seq_level_decoder.py:332-334).
+    # Never in `value`.
     opt_ms = None
     if rank == 0:
-        try:
-            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2, fused=True)
-        except (TypeError, RuntimeError):
-            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
-        snap = [p.detach().clone() for p in model.parameters()]
+        snap = opt.flat_p.clone()
         for i in range(6):
             if i == 1:
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
             opt.step()
         torch.cuda.synchronize()
         opt_ms = (time.perf_counter() - t1) / 5 * 1e3
-        with torch.no_grad():                       # leave the weights as they were for the legs below
-            for p, q in zip(model.parameters(), snap):
-                p.copy_(q)
-        del opt, snap
-        log(f"optimizer (clip 5.0 + AdamW) {opt_ms:.3f} ms/step, reported separately")
+        opt.flat_p.copy_(snap)                      # leave the weights as they were for the legs below
+        del snap
+        log(f"optimizer (clip 5.0 + AdamW, hri_emo_amd.optim.FusedClipAdamW) {opt_ms:.3f} ms/step, reported separately")
 
     roof = None
     if rank == 0 and not a.no_roofline:

@@ -32,6 +32,8 @@ _SIGS = {
     "hriemo_gate_input": ("ppppiiiipppp" + "p", "i"),
     "hriemo_sigmoid_beta": ("pppiip", "i"),
     "hriemo_fuse_fwd": ("ppppiiip", "i"),
+    "hriemo_sumsq_f32": ("plpip", "i"),
+    "hriemo_adamw_flat": ("pppplfffffifpp", "i"),
     "hriemo_masked_mean_fwd": ("ppppiiip", "i"),
     "hriemo_rowsum_f32": ("ppilp", "i"),
     "hriemo_scalar_gate_dx": ("pipippppiiip", "i"),

@@ -810,6 +810,46 @@ __global__ void scalar_gate_dx_kernel(const bf16_t* __restrict__ dH, int Lf, con
   }
 }
 
+// ------------------------------------------------------------------ optimizer (trainer step, off the timed path)
+// partial[blockIdx.x] = sum of squares of this block's grid-stride share (fixed grid: deterministic)
+__global__ __launch_bounds__(256) void sumsq_f32_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long nv = n >> 2;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+    const f32x4 t = *(const f32x4*)(x + v * 4);
+    s += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// clip_grad_norm_(max_norm) + AdamW over flat, identically laid out fp32 buffers (parameters, gradients, moments):
+// torch.nn.utils.clip_grad_norm_ (coef = min(1, max_norm / (norm + 1e-6))) followed by torch.optim.AdamW's update
+// (train_fusion_seq_level_decoder.py:332-334).  norm2 is read from device memory: no host round trip.
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                         float wd, float bc1, float bc2, float max_norm, const float* __restrict__ norm2) {
+  float coef = 1.f;
+  if (max_norm > 0.f) coef = fminf(1.f, max_norm / (sqrtf(norm2[0]) + 1e-6f));
+  const float step = lr / bc1, isb2 = 1.f / sqrtf(bc2);
+  const long nv = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    f32x4 pp = *(const f32x4*)(p + i * 4), mm = *(const f32x4*)(m + i * 4), vv = *(const f32x4*)(v + i * 4);
+    const f32x4 gg = *(const f32x4*)(g + i * 4) * coef;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pp[e] *= 1.f - lr * wd;
+      mm[e] += (gg[e] - mm[e]) * (1.f - b1);
+      vv[e] = vv[e] * b2 + gg[e] * gg[e] * (1.f - b2);
+      pp[e] -= step * mm[e] / (sqrtf(vv[e]) * isb2 + eps);
+    }
+    *(f32x4*)(p + i * 4) = pp; *(f32x4*)(m + i * 4) = mm; *(f32x4*)(v + i * 4) = vv;
+  }
+}
+
 // ---- beta gate ----
 extern "C" int hriemo_pool_chunks(int L) { return (L + 31) / 32; }
 
@@ -873,6 +913,28 @@ extern "C" int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, 
                      (bf16_t*)dX, B, L, d);
   HRIEMO_LAUNCH_CHECK("scalar_gate_dx_kernel");
   hriemo_prof_end(HP_ROWOPS, st, 2.0 * B * L * d * 2);
+  return 0;
+}
+
+extern "C" int hriemo_sumsq_f32(const float* x, long n, float* partial, int nblocks, hipStream_t st) {
+  HRIEMO_CHECK(n > 0 && n % 4 == 0 && nblocks > 0 && nblocks <= 4096, "sumsq_f32: n=%ld must be a positive multiple of 4, 0 < nblocks <= 4096", n);
+  HRIEMO_CHECK(((uintptr_t)x % 16) == 0, "sumsq_f32: unaligned buffer");
+  hipLaunchKernelGGL(sumsq_f32_kernel, dim3(nblocks), dim3(256), 0, st, x, n, partial);
+  HRIEMO_LAUNCH_CHECK("sumsq_f32_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int step, float max_norm, const float* norm2, hipStream_t st) {
+  HRIEMO_CHECK(n > 0 && n % 4 == 0 && step >= 1, "adamw_flat: n=%ld must be a positive multiple of 4 and step >= 1", n);
+  HRIEMO_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0, "adamw_flat: unaligned buffer");
+  HRIEMO_CHECK(max_norm <= 0.f || norm2 != nullptr, "adamw_flat: clipping needs the squared gradient norm");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  long gsz = (n / 4 + 255) / 256;
+  if (gsz > 4096) gsz = 4096;
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3((int)gsz), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                     max_norm, norm2);
+  HRIEMO_LAUNCH_CHECK("adamw_flat_kernel");
   return 0;
 }
 

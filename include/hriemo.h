@@ -127,6 +127,14 @@ int hriemo_masked_mean_fwd(const void* X, const unsigned char* mask, float* pool
 int hriemo_rowsum_f32(const float* x, float* out, int B, long n, hriemo_stream_t stream);
 int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, const float* dpool, const float* cnt,
                           const unsigned char* mask, void* dX, int B, int L, int d, hriemo_stream_t stream);
+/* Trainer step off the timed path, scripts/fusion/train_fusion_seq_level_decoder.py:332-334: clip_grad_norm_(5.0) +
+ * AdamW(lr 1e-4, weight_decay 1e-2) as two passes over flat fp32 buffers that share one layout (parameters,
+ * gradients, first and second moments; hri-emo_amd/optim.py lays them out): hriemo_sumsq_f32 writes nblocks partial
+ * sums of squares (reduce them with hriemo_rowsum_f32), hriemo_adamw_flat reads the squared norm from device memory
+ * (coef = min(1, max_norm/(norm+1e-6)); max_norm <= 0: no clipping) and applies torch.optim.AdamW's update. */
+int hriemo_sumsq_f32(const float* x, long n, float* partial, int nblocks, hriemo_stream_t stream);
+int hriemo_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, float max_norm, const float* norm2, hriemo_stream_t stream);
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
 int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                        const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,

@@ -449,3 +449,36 @@ def test_full_trainer_step_clip_adamw_vs_golden(H):
         errs.append((abs(dn - rn) / max(rn, 1e-12), n))
     errs.sort()
     assert errs[len(errs) // 2][0] < 2e-2 and errs[len(errs) * 9 // 10][0] < 1e-1, errs[-4:]
+
+
+def test_fused_clip_adamw_matches_torch(H):
+    """hri_emo_amd.optim.FusedClipAdamW (two HIP passes over the flat gradient / parameter / moment buffers) against
+    torch.nn.utils.clip_grad_norm_(5.0) + torch.optim.AdamW(lr 1e-4, wd 1e-2) over three trainer steps of the
+    small fusion model, same gradients on both sides (train_fusion_seq_level_decoder.py:332-334)."""
+    from hri_emo_amd.dp import GradBuckets
+    from hri_emo_amd.optim import FusedClipAdamW
+    g = load_golden("cfg1_train_p0")
+    torch.manual_seed(7)
+    m = fusion(H, 128, 4, p=0.0).train()
+    twin = {n: p.detach().clone().requires_grad_(True) for n, p in m.named_parameters()}
+    ref_opt = torch.optim.AdamW(list(twin.values()), lr=1e-4, weight_decay=1e-2)
+    buckets = GradBuckets(m.parameters(), overlap=False)
+    opt = FusedClipAdamW(buckets, lr=1e-4, weight_decay=1e-2, max_norm=5.0)
+    for step in range(3):
+        buckets.zero_grad()
+        logits, beta, _ = m(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+        (O.train_step_loss(logits, beta, cu(g["y"])) * (40.0 if step == 1 else 1.0)).backward()     # step 1 clips
+        for n, p in m.named_parameters():
+            twin[n].grad = p.grad.detach().clone()
+        tn_ref = torch.nn.utils.clip_grad_norm_(list(twin.values()), 5.0)
+        ref_opt.step()
+        tn = opt.step()
+        assert abs(float(tn) - float(tn_ref)) <= 1e-5 * float(tn_ref), (step, float(tn), float(tn_ref))
+        if step == 1:
+            assert float(tn_ref) > 5.0, "the scaled step is meant to exercise clipping"
+        for n, p in m.named_parameters():
+            err = (p.detach() - twin[n].detach()).abs().max().item()
+            assert err <= 2e-6 * max(1.0, twin[n].detach().abs().max().item()), (step, n, err)
+    # the model still runs on the re-homed parameter storage
+    with torch.no_grad():
+        m.eval()(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
