@@ -245,8 +245,33 @@ def legacy_gate_case():
         g_w2=gate.mlp[2].weight.grad, g_b2=gate.mlp[2].bias.grad, u_a=xa, u_t=xt, u_h=hu, u_beta=bu)
 
 
+def collate_case():
+    """the trainer's collate (scripts/fusion/train_fusion_seq_level_decoder.py:191-232) on ragged
+    samples whose stored masks already contain PAD tails."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_trainer", "/root/reference/scripts/fusion/train_fusion_seq_level_decoder.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                                               # reference (defines functions only)
+    g = torch.Generator().manual_seed(61)
+    d, C = 16, 4
+    las, lts, vas, vts = [9, 14, 6, 11], [5, 3, 7, 4], [7, 14, 2, 8], [5, 2, 6, 1]
+    batch, rec = [], {}
+    for i, (la, lt, va, vt) in enumerate(zip(las, lts, vas, vts)):
+        xa, xt = torch.randn(la, d, generator=g), torch.randn(lt, d, generator=g)
+        ka, kt = torch.arange(la) >= va, torch.arange(lt) >= vt
+        y = torch.zeros(C); y[i % C] = 1.0
+        batch.append((xa, ka, xt, kt, y))
+        rec.update({f"xa{i}": xa, f"ka{i}": ka, f"xt{i}": xt, f"kt{i}": kt, f"y{i}": y})
+    h_a, m_a, h_t, m_t, labels = mod.collate_seq_batch(batch, "multi_label")
+    _, _, _, _, single = mod.collate_seq_batch([(b[0], b[1], b[2], b[3], int(i % C)) for i, b in enumerate(batch)], "single_label")
+    npz("collate", h_a=h_a, mask_a=m_a, h_t=h_t, mask_t=m_t, labels=labels, single=single, **rec)
+
+
 if __name__ == "__main__":
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "collate":
+        collate_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "legacy_gate":      # add this fixture without rewriting the others
         legacy_gate_case()
         sys.exit(0)
@@ -255,3 +280,4 @@ if __name__ == "__main__":
     mosei_case()
     legacy_cases()
     legacy_gate_case()
+    collate_case()

@@ -97,3 +97,37 @@ def test_hash_rng_replica_statistics():
     a = hashrng.attn_mask(99, 3, 2, 2, 64, 64, 0.25, b_offset=0)
     b = hashrng.attn_mask(99, 3, 1, 2, 64, 64, 0.25, b_offset=1)
     assert (a[1] == b[0]).all()          # sharding-invariant: keyed on the global utterance index
+
+
+def test_collate_matches_reference_fixture_and_trim_and_bucketing():
+    """hri_emo_amd.data: the trainer's collate against outputs recorded from the reference's own collate_seq_batch
+    (tests/golden/collate.npz), trimming of all-PAD columns, and the length-bucketed sampler's invariants."""
+    import torch
+    from conftest import load_golden
+    from hri_emo_amd import data
+    g = load_golden("collate")
+    batch = [(g[f"xa{i}"], g[f"ka{i}"], g[f"xt{i}"], g[f"kt{i}"], g[f"y{i}"]) for i in range(4)]
+    h_a, m_a, h_t, m_t, labels = data.collate_seq_batch(batch, "multi_label")
+    for got, key in [(h_a, "h_a"), (m_a, "mask_a"), (h_t, "h_t"), (m_t, "mask_t"), (labels, "labels")]:
+        assert got.dtype == g[key].dtype and torch.equal(got, g[key]), key
+    single = data.collate_seq_batch([(b[0], b[1], b[2], b[3], i % 4) for i, b in enumerate(batch)], "single_label")[4]
+    assert single.dtype == torch.long and torch.equal(single, g["single"])
+    # stored masks carry PAD tails: audio valid extents 7,14,2,8 of 9,14,6,11 -> 14 stays; text 5,2,6,1 of 5,3,7,4 -> 6
+    ta, tma, tt, tmt = data.trim_padding(h_a, m_a, h_t, m_t)
+    assert ta.shape[1] == 14 and tt.shape[1] == 6 and torch.equal(ta, h_a[:, :14]) and torch.equal(tmt, m_t[:, :6])
+    assert bool(m_t[:, 6:].all()) and bool(m_a[:, 14:].all())
+    # audio is never cut below the text length (BetaGate slices h_a[:, :L_t])
+    ha2, ma2 = torch.zeros(2, 10, 4), torch.ones(2, 10, dtype=torch.bool); ma2[:, :3] = False
+    ht2, mt2 = torch.zeros(2, 8, 4), torch.zeros(2, 8, dtype=torch.bool)
+    a3, _, t3, _ = data.trim_padding(ha2, ma2, ht2, mt2)
+    assert a3.shape[1] == 8 and t3.shape[1] == 8
+    obj = {"hidden": torch.ones(5, 4, dtype=torch.float16), "attention_mask": torch.tensor([1, 1, 1, 0, 0])}
+    h, m = data.load_seq_feat(obj)
+    assert h.dtype == torch.float32 and m.tolist() == [False, False, False, True, True]
+    lengths = [int(x) for x in torch.randint(5, 400, (1003,), generator=torch.Generator().manual_seed(3))]
+    batches = data.length_bucketed_batches(lengths, 32, generator=torch.Generator().manual_seed(4))
+    flat = sorted(i for b in batches for i in b)
+    assert flat == list(range(1003)) and all(len(b) <= 32 for b in batches)
+    waste = lambda bs: sum(max(lengths[i] for i in b) * len(b) - sum(lengths[i] for i in b) for b in bs)
+    plain = [list(range(s, min(s + 32, 1003))) for s in range(0, 1003, 32)]
+    assert waste(batches) < 0.25 * waste(plain)

@@ -482,3 +482,23 @@ def test_fused_clip_adamw_matches_torch(H):
     # the model still runs on the re-homed parameter storage
     with torch.no_grad():
         m.eval()(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+
+
+def test_trimmed_batch_gives_the_same_outputs(H):
+    """dropping the columns that are PAD for every sample (data.trim_padding) must not change what
+    the model returns -- PAD keys are masked, PAD query rows feed nothing."""
+    from hri_emo_amd import data
+    torch.manual_seed(11)
+    m = fusion(H, 128, 4, p=0.0).eval()
+    B, Ta, Tt, d = 6, 80, 32, 128
+    g = torch.Generator().manual_seed(12)
+    h_a, h_t = torch.randn(B, Ta, d, generator=g), torch.randn(B, Tt, d, generator=g)
+    va, vt = torch.randint(20, 50, (B,), generator=g), torch.randint(8, 20, (B,), generator=g)
+    m_a, m_t = torch.arange(Ta)[None] >= va[:, None], torch.arange(Tt)[None] >= vt[:, None]
+    ta, tma, tt, tmt = data.trim_padding(h_a, m_a, h_t, m_t)
+    assert ta.shape[1] == int(va.max()) and tt.shape[1] == int(vt.max())
+    with torch.no_grad():
+        full = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+        trim = m(cu(ta), cu(tt), cu(tma), cu(tmt))
+    for a, b, what in zip(full, trim, ("logits", "beta", "z")):
+        close(b, a.float().cpu(), what=what)
