@@ -32,6 +32,9 @@ _SIGS = {
     "hriemo_gate_input": ("ppppiiiipppp" + "p", "i"),
     "hriemo_sigmoid_beta": ("pppiip", "i"),
     "hriemo_fuse_fwd": ("ppppiiip", "i"),
+    "hriemo_add_ln_bwd_partial_rows": ("ii", "i"),
+    "hriemo_colsum_partial_rows": ("ii", "i"),
+    "hriemo_colreduce_batch": ("pipip", "i"),
     "hriemo_sumsq_f32": ("plpip", "i"),
     "hriemo_adamw_flat": ("pppplfffffifpp", "i"),
     "hriemo_masked_mean_fwd": ("ppppiiip", "i"),

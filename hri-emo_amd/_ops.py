@@ -230,8 +230,23 @@ def linear_dw(dy, x, out, accumulate=False):
 
 def colsum(x, out, accumulate=False):
     M, N = x.shape
-    ws = workspace(_lib.lib().hriemo_colsum_workspace_bytes(M, N), x.device, slot=1)
+    L_ = _lib.lib()
+    if accumulate and DEFER_REDUCE and _in_backward():
+        rows = L_.hriemo_colsum_partial_rows(M, N)
+        part = torch.empty(rows * N, dtype=torch.float32, device=x.device)
+        _lib.call("hriemo_colsum_bf16", _p(x), x.stride(0), M, N, None, 0, _p(part), _stream())
+        _deferred.add(part, N, rows, N, 1, [out], True)
+        return
+    ws = workspace(L_.hriemo_colsum_workspace_bytes(M, N), x.device, slot=1)
     _lib.call("hriemo_colsum_bf16", _p(x), x.stride(0), M, N, _p(out), int(accumulate), _p(ws), _stream())
+
+
+def _in_backward():
+    """True while the autograd engine is running a backward pass on this thread (final callbacks can be queued)."""
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except AttributeError:
+        return False
 
 
 def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
@@ -278,10 +293,18 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
     if outs is None:
         stats = torch.empty((3, d), dtype=torch.float32, device=dev)
         outs = (stats[0], stats[1], stats[2])
-    ws = workspace(_lib.lib().hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
-    _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
-              _p(outs[1]), _p(outs[2]), int(accumulate), M, d, float(p), seed, _p(seed_word(dev)), site, row_off,
-              _p(ws), _stream())
+    L_ = _lib.lib()
+    if accumulate and DEFER_REDUCE and _in_backward():
+        rows = L_.hriemo_add_ln_bwd_partial_rows(M, d)
+        part = torch.empty(rows * 3 * d, dtype=torch.float32, device=dev)
+        _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), None,
+                  None, None, 0, M, d, float(p), seed, _p(seed_word(dev)), site, row_off, _p(part), _stream())
+        _deferred.add(part, 3 * d, rows, d, 3 if outs[2] is not None else 2, [o for o in outs if o is not None], True)
+    else:
+        ws = workspace(L_.hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
+        _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
+                  _p(outs[1]), _p(outs[2]), int(accumulate), M, d, float(p), seed, _p(seed_word(dev)), site, row_off,
+                  _p(ws), _stream())
     if dg is None:
         dg = dx           # no dropout: both branches get the same gradient
     return dx, dg, outs[0], outs[1], outs[2]
@@ -289,6 +312,48 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
 
 import os as _os
 TWIN = _os.environ.get("HRIEMO_FP32_TWIN", "1") != "0"      # carry the fp32 twin of the residual stream (LayerNorm outputs)
+
+
+DEFER_REDUCE = _os.environ.get("HRIEMO_DEFER_REDUCE", "1") != "0"
+
+
+class _DeferredReduce:
+    """Launch-boundary reduce (include/hriemo.h, hriemo_colreduce_batch): producers that accumulate straight into a
+    parameter's .grad leave their per-block partial sums behind and ONE launch at the end of backward finishes all of
+    them (85 five-microsecond launches per step otherwise).  The flush is an autograd-engine final callback: it runs
+    on the caller's stream after the engine has joined every stream backward used."""
+
+    def __init__(self):
+        self.jobs, self.keep, self.scheduled, self.blocks = [], [], False, 0
+
+    def add(self, part, pstride, np_, w, nseg, outs, accumulate):
+        gx = (w + 31) // 32
+        self.jobs.append([part.data_ptr(), pstride, np_, w, nseg | (int(bool(accumulate)) << 8) | (self.blocks << 32)]
+                         + [o.data_ptr() for o in outs] + [0] * (3 - len(outs)))
+        self.blocks += gx * nseg
+        self.keep.append(part)
+        self.keep.extend(outs)
+        self.device = part.device
+        if not self.scheduled:
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            self.scheduled = True
+
+    def flush(self):
+        jobs, n, nblocks = self.jobs, len(self.jobs), self.blocks
+        self.jobs, self.scheduled, self.blocks = [], False, 0
+        if n:
+            host = torch.tensor(jobs, dtype=torch.int64)
+            dev = torch.empty((n, 8), dtype=torch.int64, device=self.device)
+            _lib.call("hriemo_colreduce_batch", host.data_ptr(), n, _p(dev), nblocks, _stream())
+            self.keep.append(dev)
+        if not CAPTURING:           # a captured graph keeps using these buffers on every replay
+            cur = torch.cuda.current_stream(self.device)
+            for t in self.keep:     # partials of the text branch were allocated on the side stream
+                t.record_stream(cur)
+            self.keep = []
+
+
+_deferred = _DeferredReduce()
 
 
 def as_pair(x):

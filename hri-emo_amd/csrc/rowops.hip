@@ -7,6 +7,7 @@
 // Column reductions (dgamma/dbeta/dbias, pooling) are two-stage (per-block partials in a caller
 // workspace, then a fixed-order reduce) so results are bitwise reproducible.
 #include "common.h"
+#include <string.h>
 
 #define EPS_DEFAULT 1e-5f
 
@@ -270,6 +271,49 @@ static void launch_colreduce(const float* partials, long pstride, int np, Reduce
   ReduceOut tmp; tmp.o[0] = scratch; tmp.o[1] = tmp.o[2] = nullptr;
   hipLaunchKernelGGL(colreduce_kernel, dim3(gx, ng, nseg), dim3(256), 0, st, partials, pstride, np, per, tmp, (long)nseg * w, w, nseg, 0);
   hipLaunchKernelGGL(colreduce_kernel, dim3(gx, 1, nseg), dim3(256), 0, st, scratch, (long)nseg * w, ng, ng, out, 0L, w, nseg, accumulate);
+}
+
+// ---- batched second-level column reduce ("launch-boundary reduce") -------------------------------------------
+// The per-block partial sums of many producers (LayerNorm dgamma/dbeta/dbias, bias column sums) are reduced by ONE
+// launch at the end of backward instead of one or two ~5 us launches behind every producer.  Job j: np partial rows
+// of pstride floats hold nseg segments of w columns side by side; out[seg][col] (+)= sum over rows, fixed order.
+// Job record = 8 x int64: {partials, pstride, np, w, nseg | accumulate << 8 | first_block << 32, out0, out1, out2}.
+__global__ __launch_bounds__(256) void colreduce_batch_kernel(const long long* __restrict__ jobs, int njobs) {
+  __shared__ float red[8][33];
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {                                   // wave-uniform binary search on first_block
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)(jobs[mid * 8 + 4] >> 32) <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* J = jobs + lo * 8;
+  const float* partials = (const float*)J[0];
+  const long pstride = J[1];
+  const int np = (int)J[2], w = (int)J[3];
+  const long long pk = J[4];
+  const int accumulate = (int)((pk >> 8) & 0xff);
+  const int cb = (int)blockIdx.x - (int)(pk >> 32), gx = (w + 31) >> 5;
+  const int seg = cb / gx, col = (cb - seg * gx) * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < w) {
+    const float* base = partials + (long)seg * w + col;
+    int q = g;
+    for (; q + 24 < np; q += 32) {                    // four independent loads in flight per thread
+      s0 += base[(long)q * pstride];
+      s1 += base[(long)(q + 8) * pstride];
+      s2 += base[(long)(q + 16) * pstride];
+      s3 += base[(long)(q + 24) * pstride];
+    }
+    for (; q < np; q += 8) s0 += base[(long)q * pstride];
+  }
+  red[g][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && col < w) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    float* o = (float*)J[5 + seg] + col;
+    *o = accumulate ? *o + t : t;
+  }
 }
 
 // column sums of a bf16 [M,N] matrix (bias grads): per-(slice) partials
@@ -703,12 +747,15 @@ extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, c
 #undef CALL
   HRIEMO_LAUNCH_CHECK("add_ln_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, 5.0 * M * d * 2);
+  if (dgamma == nullptr) return 0;      // caller reduces the [nb][3d] partials later (hriemo_colreduce_batch)
   float* scratch = workspace + (long)nb * 3 * d;
   ReduceOut ro; ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = dbias;
   launch_colreduce(workspace, (long)3 * d, nb, ro, d, dbias != nullptr ? 3 : 2, accumulate, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
 }
+
+extern "C" int hriemo_add_ln_bwd_partial_rows(int M, int d) { (void)d; return row_grid(M, 1024); }
 
 static int colsum_slices(int M, int N) {
   const int ncg = (N / 8 + 63) / 64;
@@ -726,9 +773,35 @@ extern "C" int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* 
   const int slices = colsum_slices(M, N);
   const int rps = (M + slices - 1) / slices;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(ncg, slices), dim3(64), 0, st, (const bf16_t*)X, ldx, M, N, rps, workspace);
+  if (out == nullptr) { HRIEMO_LAUNCH_CHECK("colsum_partial_kernel"); return 0; }   // [slices][N] partials left for hriemo_colreduce_batch
   ReduceOut ro; ro.o[0] = out; ro.o[1] = ro.o[2] = nullptr;
   launch_colreduce(workspace, (long)N, slices, ro, N, 1, accumulate, workspace + (long)slices * N, st);
   HRIEMO_LAUNCH_CHECK("colsum");
+  return 0;
+}
+
+extern "C" int hriemo_colsum_partial_rows(int M, int N) { return colsum_slices(M, N); }
+
+// job records travel host -> device as kernel ARGUMENTS (48 records = 3 KB per launch): no pinned staging buffer,
+// nothing a stream capture could object to, and the values are baked into a captured graph
+struct JobChunk { long long v[48 * 8]; };
+__global__ void upload_jobs_kernel(const JobChunk c, long long* __restrict__ dst, int n) {
+  for (int i = threadIdx.x; i < n * 8; i += blockDim.x) dst[i] = c.v[i];
+}
+
+extern "C" int hriemo_colreduce_batch(const void* jobs_host, int njobs, void* jobs_dev, int nblocks, hipStream_t st) {
+  HRIEMO_CHECK(jobs_host != nullptr && jobs_dev != nullptr && njobs > 0 && nblocks > 0, "colreduce_batch: empty job table");
+  for (int j0 = 0; j0 < njobs; j0 += 48) {
+    JobChunk c;
+    const int n = njobs - j0 < 48 ? njobs - j0 : 48;
+    memcpy(c.v, (const long long*)jobs_host + (long)j0 * 8, (size_t)n * 64);
+    hipLaunchKernelGGL(upload_jobs_kernel, dim3(1), dim3(256), 0, st, c, (long long*)jobs_dev + (long)j0 * 8, n);
+  }
+  HRIEMO_LAUNCH_CHECK("upload_jobs_kernel");
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(colreduce_batch_kernel, dim3(nblocks), dim3(256), 0, st, (const long long*)jobs_dev, njobs);
+  HRIEMO_LAUNCH_CHECK("colreduce_batch_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, 0.0);
   return 0;
 }
 

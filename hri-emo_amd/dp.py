@@ -45,6 +45,8 @@ class GradBuckets:
         self._works = []
         self._hooks = []
         if overlap and self.world > 1:
+            from . import _ops
+            _ops.DEFER_REDUCE = False        # buckets are all-reduced as soon as their last gradient is written: no deferral
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 p._hriemo_grad_ready = self._on_grad     # gradients the kernels accumulate in place (_ops.GradSink)

@@ -135,6 +135,16 @@ int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, c
 int hriemo_sumsq_f32(const float* x, long n, float* partial, int nblocks, hriemo_stream_t stream);
 int hriemo_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int step, float max_norm, const float* norm2, hriemo_stream_t stream);
+/* Launch-boundary reduce.  hriemo_add_ln_bwd with dgamma == NULL and hriemo_colsum_bf16 with out == NULL stop after
+ * their per-block partial sums ([hriemo_add_ln_bwd_partial_rows(M,d)][3*d] resp. [hriemo_colsum_partial_rows(M,N)][N]
+ * fp32 at the start of the caller's workspace); hriemo_colreduce_batch finishes any number of such jobs in one launch
+ * at the end of backward.  jobs_host: HOST array of njobs records (copied into the caller's device buffer jobs_dev,
+ * njobs*64 bytes, through kernel arguments: capture-safe) of 8 x int64 = {partials, pstride (floats), np, w,
+ * nseg | accumulate << 8 | first_block << 32, out0, out1, out2} with first_block the running sum of
+ * nseg * ceil(w/32) over the preceding jobs and nblocks the total.  Deterministic (fixed summation order). */
+int hriemo_add_ln_bwd_partial_rows(int M, int d);
+int hriemo_colsum_partial_rows(int M, int N);
+int hriemo_colreduce_batch(const void* jobs_host, int njobs, void* jobs_dev, int nblocks, hriemo_stream_t stream);
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
 int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                        const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,

@@ -275,7 +275,9 @@ def test_fused_weight_grad_accumulation_matches_autograd_path(H):
     step()                                                   # fused: kernels accumulate in place
     for n, p in m.named_parameters():
         assert p.grad.data_ptr() >= buckets.flat.data_ptr(), n
-        assert torch.equal(p.grad, ref[n]), (n, (p.grad - ref[n]).abs().max().item())
+        # same partial sums, but the launch-boundary reduce adds them in another (fixed) order than the in-place one
+        err = (p.grad - ref[n]).abs().max().item()
+        assert err <= 1e-6 * max(1.0, ref[n].abs().max().item()), (n, err)
     step()                                                   # no zeroing: must now hold twice the gradient
     for n, p in m.named_parameters():
         err = (p.grad - 2 * ref[n]).abs().max().item()
