@@ -490,7 +490,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         // 64x64 wave tiles: two full fragment sets, reads of the next half-step trickle between the MFMAs
         load_frags(smem + cur * STAGE, 0, afA, bfA);
         for (int it = 0; it < nk; ++it) {
-          const bool issued = prefetch(it);
+          prefetch(it);
           __builtin_amdgcn_sched_barrier(0);
           load_frags(smem + cur * STAGE, 1, afB, bfB);
           mma(afA, bfA);
@@ -501,8 +501,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           if (it + 1 < nk) {
             // stage it+1 must have landed for every wave; our own reads of stage `it` must be retired before
             // any wave may restage that slot (WAR).
-            if (issued) wait_vmcnt<(NS - 2) * LPT>();
-            else wait_vmcnt<0>();
+            retire_next(it);
             __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);        // reads + MFMAs in ONE scheduling region
@@ -524,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         //   read next A-set | MFMA(B-set)
         load_frags(smem + cur * STAGE, 0, afA, bfA);
         for (int it = 0; it < nk; ++it) {
-          const bool issued = prefetch(it);
+          prefetch(it);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_setprio(1);
           mma_rows(afA, bfA, 0, MT / 2);
@@ -539,8 +538,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           cur = (cur + 1 == NS) ? 0 : cur + 1;
           nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
           if (it + 1 < nk) {
-            if (issued) wait_vmcnt<(NS - 2) * LPT>();
-            else wait_vmcnt<0>();
+            retire_next(it);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
             load_frags(smem + cur * STAGE, 0, afA, bfA);
@@ -587,7 +585,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         load_a(smem + cur * STAGE, 0, 0, a0);
         load_b(smem + cur * STAGE, 0, b0);
         for (int it = 0; it < nk; ++it) {
-          const bool issued = prefetch(it);
+          prefetch(it);
           const char* sa = smem + cur * STAGE;
           __builtin_amdgcn_sched_barrier(0);
           load_a(sa, 0, 1, a1);
@@ -600,8 +598,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           cur = (cur + 1 == NS) ? 0 : cur + 1;
           nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
           if (it + 1 < nk) {
-            if (issued) wait_vmcnt<(NS - 2) * LPT>();
-            else wait_vmcnt<0>();
+            retire_next(it);
             __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): a1 is in, slot released
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -665,7 +662,7 @@ static const TileCfg kCfg[] = {
     {128, 128, 256, 2 * 32768, 2, 64},   // 0: 128x128, 2x2 waves (64x64 per wave), 2 stages, two blocks per CU
     {256, 128, 512, 3 * 49152, 3, 64},   // 1: 256x128, 4x2 waves (64x64 per wave), 3 stages
     {256, 256, 512, 2 * 65536, 2, 64},   // 2: 256x256, 2x4 waves (128x64 per wave), 2 stages
-    {64, 128, 256, 2 * 24576, 2, 64},    // 3: 64x128, 2x2 waves (32x64 per wave), 2 stages: small-M problems
+    {64, 128, 256, 4 * 24576, 4, 64},    // 3: 64x128, 2x2 waves (32x64 per wave), 4 stages: small-M, latency-bound problems
     {256, 256, 512, 4 * 32768, 4, 32},   // 4: 256x256, 2x4 waves, 4 stages of 32 k, staggered two-group schedule
 };
 static const int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
@@ -706,7 +703,7 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     case 1: launch_one<TA, TB, OUTF32, 256, 128, 4, 2, 3>(a, lds, st); break;
     case 2: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 2>(a, lds, st); break;
     case 4: launch_one<TA, TB, OUTF32, 256, 256, 2, 4, 4, 32>(a, lds, st); break;
-    default: launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 2>(a, lds, st); break;
+    default: launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 4>(a, lds, st); break;
   }
 }
 
