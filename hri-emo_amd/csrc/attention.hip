@@ -138,10 +138,11 @@ template <int HD, int NW, int QW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * STRIDE + 64 * 4];
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * STRIDE + 64 * 4 + 16];
   char* Kt = lds;
   char* Vt = lds + 64 * STRIDE;
   float* mb = (float*)(lds + 2 * 64 * STRIDE);
+  int* padflag = (int*)(lds + 2 * 64 * STRIDE + 64 * 4);       // does the current key tile contain PAD keys?
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
       const int key = kt * 64 + tid;
       const bool pad = key >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
       mb[tid] = pad ? -INFINITY : 0.f;
+      const bool anyp = __builtin_amdgcn_ballot_w64(pad) != 0;
+      if (tid == 0) padflag[0] = anyp ? 1 : 0;
     }
     __syncthreads();
     if (PF && kt + 1 < nkt) {
@@ -214,48 +217,63 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
         for (int qs = 0; qs < QW; ++qs) s[qs][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][ks], s[qs][n], 0, 0, 0);
       }
 
+    const bool has_pad = padflag[0] != 0;          // block-uniform
 #pragma unroll
     for (int qs = 0; qs < QW; ++qs) {
+      // scores stay RAW (unscaled) until the exponent: scale > 0 commutes with the maximum, and
+      // p = exp2(s*sl2 - m) is then one fma + one exp per element.  Only tiles with PAD keys add the -inf bias.
       float mx = -INFINITY;
+      if (has_pad) {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
+        for (int n = 0; n < 4; ++n) {
+          const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s[qs][n][r] = s[qs][n][r] * sl2 + bias[r];
-          mx = fmaxf(mx, s[qs][n][r]);
+          for (int r = 0; r < 4; ++r) s[qs][n][r] += bias[r];
         }
       }
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qs][n][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx *= sl2;                                     // -inf stays -inf
+      // Deferred rescale: m[qs] is the reference exponent the running sums are expressed in, not the running
+      // maximum.  It only moves (and O, l are only rescaled) when some query of the wave has grown past it by more
+      // than 8 in log2 units, so p stays <= 2^8 and most key tiles skip the 48-register rescale of O altogether.
       const float mnew = fmaxf(m[qs], mx);
-      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = EXP2(m[qs] - msafe);
-      m[qs] = mnew;
+      if (__builtin_amdgcn_ballot_w64(mnew > m[qs] + 8.f) != 0) {     // wave-uniform; -inf + 8 = -inf: first valid tile
+        const float ms = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = EXP2(m[qs] - ms);
+        m[qs] = mnew;
+        l[qs] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qs][dt] *= alpha;
+      }
+      const float nm = (m[qs] == -INFINITY) ? 0.f : -m[qs];
       float rs = 0.f;
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = EXP2(s[qs][n][r] - msafe);
+          const float p = EXP2(fmaf(s[qs][n][r], sl2, nm));
           s[qs][n][r] = p;
           rs += p;
         }
       rs += __shfl_xor(rs, 16);
       rs += __shfl_xor(rs, 32);
-      l[qs] = l[qs] * alpha + rs;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[qs][dt] *= alpha;
+      l[qs] += rs;
       if (a.thr16 != 0) {
-        // keys 4g..4g+3 of each 16-key subtile = two hash pairs; one multiply-free step per extra pair
+        // keys 4g..4g+3 of each 16-key subtile = two hash pairs; one multiply-free step per extra pair.  The
+        // 1/(1-p) factor of the kept probabilities is applied once, to O, after the last key tile.
         const uint32_t hb = drop_base(key32, (uint32_t)(qbase + qs * 16 + i), (uint32_t)((kt * 64 + 4 * g) >> 1));
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
             const uint32_t x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
-            s[qs][n][2 * pr] = keep_lo(x, a.thr16) ? s[qs][n][2 * pr] * a.inv_keep : 0.f;
-            s[qs][n][2 * pr + 1] = keep_hi(x, a.thr16) ? s[qs][n][2 * pr + 1] * a.inv_keep : 0.f;
+            s[qs][n][2 * pr] = keep_lo(x, a.thr16) ? s[qs][n][2 * pr] : 0.f;
+            s[qs][n][2 * pr + 1] = keep_hi(x, a.thr16) ? s[qs][n][2 * pr + 1] : 0.f;
           }
       }
     }
@@ -280,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   for (int qs = 0; qs < QW; ++qs) {
     const int q = qbase + qs * 16 + i;
     if (q >= a.Lq) continue;
-    const float inv = 1.f / l[qs];   // l == 0 (all keys PAD) -> 0 * inf = NaN, as the reference
+    const float inv = (a.thr16 != 0 ? a.inv_keep : 1.f) / l[qs];   // l == 0 (all keys PAD) -> 0 * inf = NaN, as the reference
     bf16_t* op = a.O + ((long)b * a.Lq + q) * a.ldo + h * HD + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
