@@ -97,11 +97,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    # rehearsal on a one-GPU box (control flow of the N>1 path only, never a measurement): HRIEMO_DIST_BACKEND=gloo lets
+    # several ranks share device 0 and exchange gradients through the host
+    backend = os.environ.get("HRIEMO_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = min(local, torch.cuda.device_count() - 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import hri_emo_amd as H
     from hri_emo_amd import _lib
