@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
   const int nkt = (a.Lk + 63) >> 6;
 
-  constexpr bool PF = false;              // measured: the prefetch helps dQ / dK,dV (-25 %) but not the forward
+  constexpr bool PF = true;               // register prefetch of the next K/V tile
   TileRegs<HD, 64, NT> kr, vr;
   if (PF) {
     tile_fetch<HD, 64, NT>(kr, Kb, a.ldk, 0, a.Lk, tid);
@@ -365,6 +365,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
     for (int dt = 0; dt < DT; ++dt) dq[qs][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float sl2 = a.scale * LOG2E;
+  float cexp[QW], dlk[QW];
+#pragma unroll
+  for (int qs = 0; qs < QW; ++qs) {
+    cexp[qs] = (a.thr16 != 0 ? log2f(a.inv_keep) : 0.f) - lse2[qs];
+    dlk[qs] = a.thr16 != 0 ? dl[qs] / a.inv_keep : dl[qs];
+  }
   const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
   const bf16_t* Kb = a.K + (long)b * a.Lk * a.ldk + h * HD;
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
@@ -429,10 +435,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int r = 2 * pr + e;
-            const float p = EXP2(s[qs][n][r] * sl2 + bias[r] - lse2[qs]);
+            // pk = p / (1 - p_drop): the dropout scale rides in the exponent's constant, delta is pre-scaled by
+            // (1 - p_drop), so dS = pk * (keep ? dP : 0  -  delta') is one fma + exp + select + sub + mul
+            const float pk = EXP2(fmaf(s[qs][n][r], sl2, bias[r] + cexp[qs]));
             float dpd = dp[qs][n][r];
-            if (a.thr16 != 0) dpd = (e ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16)) ? dpd * a.inv_keep : 0.f;
-            s[qs][n][r] = p * (dpd - dl[qs]);
+            if (a.thr16 != 0) dpd = (e ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16)) ? dpd : 0.f;
+            s[qs][n][r] = pk * (dpd - dlk[qs]);
           }
         }
       }
@@ -520,6 +528,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   const long lbase = ((long)b * a.H + h) * a.Lq;
   const int nqt = (a.Lq + 31) >> 5;
 
+  const float l2ik = a.thr16 != 0 ? log2f(a.inv_keep) : 0.f, keepfrac = a.thr16 != 0 ? 1.f / a.inv_keep : 1.f;
   constexpr bool PF = (NW == 4);
   TileRegs<HD, 32, NT> qr, dor;
   if (PF) {
@@ -537,8 +546,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
     }
     if (tid < 32) {
       const int q = qt * 32 + tid;
-      lse_s[tid] = q < a.Lq ? a.lse[lbase + q] * LOG2E : INFINITY;   // +inf -> p = 0 for rows past Lq
-      del_s[tid] = q < a.Lq ? a.delta[lbase + q] : 0.f;
+      lse_s[tid] = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
+      del_s[tid] = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
     }
     __syncthreads();
     if (PF && qt + 1 < nqt) {
@@ -569,6 +578,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
     bf16x8 pf[KW], dsf[KW];
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
+      // lse_s holds (log2(1/(1-p_drop)) - lse*log2e), del_s holds delta*(1-p_drop): pk = p/(1-p_drop) straight
+      // from the exponent, P~ = keep ? pk : 0, dS = pk * (keep ? dP : 0  -  delta')
       const f32x4 lse4 = *(LDS_PTR(const f32x4))(lse_s + qs * 16 + 4 * g);
       const f32x4 del4 = *(LDS_PTR(const f32x4))(del_s + qs * 16 + 4 * g);
 #pragma unroll
@@ -576,17 +587,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
         const uint32_t key = (uint32_t)(kbase + kw * 16 + i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = kvalid[kw] ? EXP2(s[kw][qs][r] * sl2 - lse4[r]) : 0.f;
-          float pd = p, dpd = dp[kw][qs][r];
+          const float pk = kvalid[kw] ? EXP2(fmaf(s[kw][qs][r], sl2, lse4[r])) : 0.f;
+          float pd = pk, dpd = dp[kw][qs][r];
           if (a.thr16 != 0) {
             // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
             const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * 32 + qs * 16 + 4 * g + r) * DROP_CA);
             const bool keep = (key & 1u) ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16);
-            pd = keep ? p * a.inv_keep : 0.f;
-            dpd = keep ? dpd * a.inv_keep : 0.f;
+            pd = keep ? pk : 0.f;
+            dpd = keep ? dpd : 0.f;
           }
           pf[kw][qs * 4 + r] = (bf16_t)pd;
-          dsf[kw][qs * 4 + r] = (bf16_t)(p * (dpd - del4[r]));
+          dsf[kw][qs * 4 + r] = (bf16_t)(pk * (dpd - del4[r]));
         }
       }
     }
