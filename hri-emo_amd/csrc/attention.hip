@@ -113,6 +113,10 @@ __device__ __forceinline__ void tile_commit(const TileRegs<HD, NR, NT>& t, char*
   }
 }
 
+#ifndef DKV_QT
+#define DKV_QT 32        // query rows per tile of the dK/dV kernel (64 was measured: +33 % time, the staging registers cost a wave per SIMD)
+#endif
+
 // XCD-aware block -> (tile, batch*head) map.  Blocks are dealt round-robin over the 8 XCDs (private L2s), so
 // with the natural (tile fastest) order the tiles of one (batch, head) land on 8 different L2s and each
 // re-fetches that head's K/V (or Q/dO) through the fabric: 230-390 MB per launch measured (profiles/
@@ -476,15 +480,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <int HD, int NW, int KW>
+template <int HD, int NW, int KW, int QT>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char lds[2 * 32 * STRIDE + 2 * 32 * 4];
+  static_assert(QT == 32 || QT == 64, "query tile");
+  constexpr int NQS = QT / 16, NKQ = QT / 32;
+  __shared__ __attribute__((aligned(16))) char lds[2 * QT * STRIDE + 2 * QT * 4];
   char* Qt = lds;
-  char* dOt = lds + 32 * STRIDE;
-  float* lse_s = (float*)(lds + 2 * 32 * STRIDE);
-  float* del_s = lse_s + 32;
+  char* dOt = lds + QT * STRIDE;
+  float* lse_s = (float*)(lds + 2 * QT * STRIDE);
+  float* del_s = lse_s + QT;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
@@ -526,45 +532,45 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
   const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
   const long lbase = ((long)b * a.H + h) * a.Lq;
-  const int nqt = (a.Lq + 31) >> 5;
+  const int nqt = (a.Lq + QT - 1) / QT;
 
   const float l2ik = a.thr16 != 0 ? log2f(a.inv_keep) : 0.f, keepfrac = a.thr16 != 0 ? 1.f / a.inv_keep : 1.f;
   constexpr bool PF = (NW == 4);
-  TileRegs<HD, 32, NT> qr, dor;
+  TileRegs<HD, QT, NT> qr, dor;
   if (PF) {
-    tile_fetch<HD, 32, NT>(qr, Qb, a.ldq, 0, a.Lq, tid);
-    tile_fetch<HD, 32, NT>(dor, dOb, a.lddo, 0, a.Lq, tid);
+    tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, 0, a.Lq, tid);
+    tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, 0, a.Lq, tid);
   }
   for (int qt = 0; qt < nqt; ++qt) {
     __syncthreads();
     if (PF) {
-      tile_commit<HD, 32, NT>(qr, Qt, tid);
-      tile_commit<HD, 32, NT>(dor, dOt, tid);
+      tile_commit<HD, QT, NT>(qr, Qt, tid);
+      tile_commit<HD, QT, NT>(dor, dOt, tid);
     } else {
-      load_tile<HD, 32, NT>(Qt, Qb, a.ldq, qt * 32, a.Lq, tid);
-      load_tile<HD, 32, NT>(dOt, dOb, a.lddo, qt * 32, a.Lq, tid);
+      load_tile<HD, QT, NT>(Qt, Qb, a.ldq, qt * QT, a.Lq, tid);
+      load_tile<HD, QT, NT>(dOt, dOb, a.lddo, qt * QT, a.Lq, tid);
     }
-    if (tid < 32) {
-      const int q = qt * 32 + tid;
+    if (tid < QT) {
+      const int q = qt * QT + tid;
       lse_s[tid] = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
       del_s[tid] = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
     }
     __syncthreads();
     if (PF && qt + 1 < nqt) {
-      tile_fetch<HD, 32, NT>(qr, Qb, a.ldq, (qt + 1) * 32, a.Lq, tid);
-      tile_fetch<HD, 32, NT>(dor, dOb, a.lddo, (qt + 1) * 32, a.Lq, tid);
+      tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, (qt + 1) * QT, a.Lq, tid);
+      tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, (qt + 1) * QT, a.Lq, tid);
     }
 
-    f32x4 s[KW][2], dp[KW][2];
+    f32x4 s[KW][NQS], dp[KW][NQS];
 #pragma unroll
     for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
+      for (int qs = 0; qs < NQS; ++qs) {
         s[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
         dp[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs)
+    for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 qfr = row_frag(Qt, STRIDE, qs * 16 + i, ks * 4 + g);
@@ -575,9 +581,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
           dp[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vreg[kw][ks], dp[kw][qs], 0, 0, 0);
         }
       }
-    bf16x8 pf[KW], dsf[KW];
+    bf16x8 pf[KW][NKQ], dsf[KW][NKQ];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
+    for (int qs = 0; qs < NQS; ++qs) {
       // lse_s holds (log2(1/(1-p_drop)) - lse*log2e), del_s holds delta*(1-p_drop): pk = p/(1-p_drop) straight
       // from the exponent, P~ = keep ? pk : 0, dS = pk * (keep ? dP : 0  -  delta')
       const f32x4 lse4 = *(LDS_PTR(const f32x4))(lse_s + qs * 16 + 4 * g);
@@ -591,26 +597,28 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
           float pd = pk, dpd = dp[kw][qs][r];
           if (a.thr16 != 0) {
             // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
-            const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * 32 + qs * 16 + 4 * g + r) * DROP_CA);
+            const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * QT + qs * 16 + 4 * g + r) * DROP_CA);
             const bool keep = (key & 1u) ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16);
             pd = keep ? pk : 0.f;
             dpd = keep ? dpd : 0.f;
           }
-          pf[kw][qs * 4 + r] = (bf16_t)pd;
-          dsf[kw][qs * 4 + r] = (bf16_t)(pk * (dpd - del4[r]));
+          pf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)pd;
+          dsf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)(pk * (dpd - del4[r]));
         }
       }
     }
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      const bf16x8 dotf = tr_frag(dOt, STRIDE, 0, dt * 16, lane);
-      const bf16x8 qtf = tr_frag(Qt, STRIDE, 0, dt * 16, lane);
+    for (int kq = 0; kq < NKQ; ++kq)
 #pragma unroll
-      for (int kw = 0; kw < KW; ++kw) {
-        dv[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf[kw], dv[kw][dt], 0, 0, 0);
-        dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw], dk[kw][dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8 dotf = tr_frag(dOt, STRIDE, 32 * kq, dt * 16, lane);
+        const bf16x8 qtf = tr_frag(Qt, STRIDE, 32 * kq, dt * 16, lane);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          dv[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf[kw][kq], dv[kw][dt], 0, 0, 0);
+          dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw][kq], dk[kw][dt], 0, 0, 0);
+        }
       }
-    }
   }
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw) {
@@ -784,15 +792,15 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   hriemo_prof_end(HP_ATTN_BWD_DQ, st, 6.0 * B * H * (double)Lq * Lk * head_dim);
   hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
   if (Lk > 64 && attn_wide(1)) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else if (Lk > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, DKV_QT>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1>), dim3(B * H), dim3(64), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32>), dim3(B * H), dim3(64), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   }
