@@ -172,6 +172,50 @@ def main():
         del snap
         log(f"optimizer (clip 5.0 + AdamW, hri_emo_amd.optim.FusedClipAdamW) {opt_ms:.3f} ms/step, reported separately")
 
+    # north_star sub-target: the cross-attention QK^T / AV cores alone (both directions, dropout as in the step),
+    # algorithmic FLOPs (fwd 4*B*H*Lq*Lk*hd, bwd 2x) over the kernels' own time, against the dense bf16 MFMA peak and
+    # against the attention roofline min(MFMA peak, AI * HBM) with AI = Lq*Lk/(Lq+Lk) flop/B
+    xattn = None
+    if rank == 0 and not a.no_roofline:
+        from hri_emo_amd import _ops
+        Hh, hd = CFG["n_heads"], CFG["d_model"] // CFG["n_heads"]
+        pd = CFG["dropout"]
+
+        def t_us(fn, reps=20):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+
+        xattn = {"dropout": pd, "peak_tflops": PEAK_BF16_TFLOPS, "directions": {}}
+        tot_fl, tot_us = 0.0, 0.0
+        for name, Lq, Lk in (("audio_queries_text", T_A, T_T), ("text_queries_audio", T_T, T_A)):
+            q = torch.randn(B * Lq, CFG["d_model"], device=device).bfloat16()
+            k = torch.randn(B * Lk, CFG["d_model"], device=device).bfloat16()
+            v = torch.randn(B * Lk, CFG["d_model"], device=device).bfloat16()
+            o, lse = _ops.attn_fwd(q, k, v, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0)
+            do, dq, dk, dv = torch.randn_like(o), torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            tf = t_us(lambda: _ops.attn_fwd(q, k, v, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0))
+            tb = t_us(lambda: _ops.attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0))
+            fl = 4.0 * B * Hh * Lq * Lk * hd
+            roofl = min(PEAK_BF16_TFLOPS, Lq * Lk / (Lq + Lk) * 8.0)
+            xattn["directions"][name] = {"fwd_us": round(tf, 1), "bwd_us": round(tb, 1),
+                                         "fwd_tflops": round(fl / tf / 1e6, 1), "fwd_bwd_tflops": round(3 * fl / (tf + tb) / 1e6, 1),
+                                         "attention_roofline_tflops": round(roofl, 1)}
+            tot_fl += 3 * fl
+            tot_us += tf + tb
+        xattn["fwd_bwd_tflops"] = round(tot_fl / tot_us / 1e6, 1)
+        xattn["frac_of_mfma_peak"] = round(tot_fl / tot_us / 1e6 / PEAK_BF16_TFLOPS, 4)
+        xattn["frac_of_attention_roofline"] = round(tot_fl / tot_us / 1e6 / min(PEAK_BF16_TFLOPS, T_A * T_T / (T_A + T_T) * 8.0), 4)
+        log(f"cross-attention cores fwd+bwd: {xattn['fwd_bwd_tflops']} TFLOP/s = {100 * xattn['frac_of_mfma_peak']:.1f} % of MFMA peak, "
+            f"{100 * xattn['frac_of_attention_roofline']:.1f} % of the attention roofline")
+
     roof = None
     if rank == 0 and not a.no_roofline:
         L = _lib.lib()
@@ -222,7 +266,7 @@ def main():
                           "grad_allreduce": "fp32 flat buckets 32MiB, RCCL" if world > 1 else "none",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "streams": 2 if os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0" else 1},
-               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3),
+               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn,
                "model_tflops": round(value * FLOP_PER_UTT_FWD_BWD / 1e12, 1),
                "model_mfma_frac": round(value * FLOP_PER_UTT_FWD_BWD / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
         if roof is not None:

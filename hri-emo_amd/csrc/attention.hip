@@ -699,9 +699,10 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a) {
 // per wave (K/V fragment reuse), the backward kernels with one (128 instead of ~220 VGPRs -> twice the
 // waves per SIMD to cover their long VALU chains, and less padding waste at L=400).
 static int attn_wide(int backward) {
-  static int v = -1;
+  static int v = -1, f = -1;
   if (v < 0) { const char* e = getenv("HRIEMO_ATTN_WIDE_BWD"); v = (e && e[0] == '1') ? 1 : 0; }
-  return backward ? v : 1;
+  if (f < 0) { const char* e = getenv("HRIEMO_ATTN_WIDE_FWD"); f = (e && e[0] == '0') ? 0 : 1; }
+  return backward ? v : f;
 }
 static int check_common(const AttnArgs& a, int hd) {
   HRIEMO_CHECK(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "attn: empty problem");
