@@ -486,12 +486,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32 || QT == 64, "query tile");
   constexpr int NQS = QT / 16, NKQ = QT / 32;
-  __shared__ __attribute__((aligned(16))) char lds[2 * QT * STRIDE + 2 * QT * 4];
-  char* Qt = lds;
-  char* dOt = lds + QT * STRIDE;
-  float* lse_s = (float*)(lds + 2 * QT * STRIDE);
-  float* del_s = lse_s + QT;
-
+  // two LDS images of the (Q, dO, lse, delta) tile: the next tile is committed while the current one is consumed,
+  // so a query tile costs ONE barrier instead of two and the LDS stores overlap the MFMAs
+  constexpr int TILE_BYTES = 2 * QT * STRIDE + 2 * QT * 4;
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
   tile_and_head((a.Lk + NW * KW * 16 - 1) / (NW * KW * 16), a.B * a.H, tile, bh);
@@ -537,28 +535,37 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
   const float l2ik = a.thr16 != 0 ? log2f(a.inv_keep) : 0.f, keepfrac = a.thr16 != 0 ? 1.f / a.inv_keep : 1.f;
   constexpr bool PF = (NW == 4);
   TileRegs<HD, QT, NT> qr, dor;
-  if (PF) {
-    tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, 0, a.Lq, tid);
-    tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, 0, a.Lq, tid);
-  }
-  for (int qt = 0; qt < nqt; ++qt) {
-    __syncthreads();
-    if (PF) {
-      tile_commit<HD, QT, NT>(qr, Qt, tid);
-      tile_commit<HD, QT, NT>(dor, dOt, tid);
-    } else {
-      load_tile<HD, QT, NT>(Qt, Qb, a.ldq, qt * QT, a.Lq, tid);
-      load_tile<HD, QT, NT>(dOt, dOb, a.lddo, qt * QT, a.Lq, tid);
-    }
+  float lse_r = 0.f, del_r = 0.f;                 // lse / delta of query row `tid` of the tile in flight (tid < QT)
+  auto fetch = [&](int qt) {
+    tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, qt * QT, a.Lq, tid);
+    tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, qt * QT, a.Lq, tid);
     if (tid < QT) {
       const int q = qt * QT + tid;
-      lse_s[tid] = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
-      del_s[tid] = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
+      lse_r = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
+      del_r = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
     }
-    __syncthreads();
-    if (PF && qt + 1 < nqt) {
-      tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, (qt + 1) * QT, a.Lq, tid);
-      tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, (qt + 1) * QT, a.Lq, tid);
+  };
+  auto commit = [&](int buf) {
+    char* base = lds + buf * TILE_BYTES;
+    tile_commit<HD, QT, NT>(qr, base, tid);
+    tile_commit<HD, QT, NT>(dor, base + QT * STRIDE, tid);
+    if (tid < QT) {
+      ((float*)(base + 2 * QT * STRIDE))[tid] = lse_r;
+      ((float*)(base + 2 * QT * STRIDE))[QT + tid] = del_r;
+    }
+  };
+  fetch(0);
+  commit(0);
+  if (nqt > 1) fetch(1);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const char* Qt = lds + (qt & 1) * TILE_BYTES;
+    const char* dOt = Qt + QT * STRIDE;
+    const float* lse_s = (const float*)(Qt + 2 * QT * STRIDE);
+    const float* del_s = lse_s + QT;
+    if (qt + 1 < nqt) {
+      commit((qt + 1) & 1);                       // image last read in iteration qt-1, released by its closing barrier
+      if (qt + 2 < nqt) fetch(qt + 2);
     }
 
     f32x4 s[KW][NQS], dp[KW][NQS];
@@ -619,6 +626,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
           dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw][kq], dk[kw][dt], 0, 0, 0);
         }
       }
+    __syncthreads();
   }
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw) {
