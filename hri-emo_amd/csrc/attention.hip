@@ -91,15 +91,21 @@ template <int HD, int NR, int NT> struct TileRegs {
   static constexpr int NPT = (NR * AttnGeom<HD>::CHP + NT - 1) / NT;
   bf16x8 v[NPT];
 };
+// Raw-buffer loads: rows past the end of the sequence (and the padding chunks of the LDS image) carry an offset beyond
+// num_records and come back as zeros from the hardware range check -- no EXEC-mask branches around the loads.
 template <int HD, int NR, int NT>
 __device__ __forceinline__ void tile_fetch(TileRegs<HD, NR, NT>& t, const bf16_t* base, long ld, int row_first, int nrows_total, int tid) {
   using G = AttnGeom<HD>;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)row_first * ld), 0, (int)0x80000000u, 0x00020000);
+  const int nleft = nrows_total - row_first;
 #pragma unroll
   for (int k = 0; k < TileRegs<HD, NR, NT>::NPT; ++k) {
     const int id = tid + k * NT;
     const int r = id / G::CHP, c = id - r * G::CHP;
-    t.v[k] = zero8();
-    if (id < NR * G::CHP && row_first + r < nrows_total && c < G::CH) t.v[k] = *(const bf16x8*)(base + (long)(row_first + r) * ld + c * 8);
+    const bool ok = id < NR * G::CHP && r < nleft && c < G::CH;
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (int)((r * ld + c * 8) * 2) : (int)0x80000000u, 0, 0);
+    t.v[k] = __builtin_bit_cast(bf16x8, v);
   }
 }
 template <int HD, int NR, int NT>
