@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
+    ap.add_argument("--graph-dp", action="store_true", help="N>1: replay a captured step and all-reduce afterwards (no overlap)")
     return ap.parse_args()
 
 
@@ -118,7 +119,10 @@ def main():
 
     torch.manual_seed(1234)                       # same weights and same dropout-seed stream on every rank
     model = H.FusionWithEmotionDecoder(**CFG).to(device).train()
-    use_graph = not a.no_graph
+    # one GPU: the whole step is one hipGraph replay.  Several GPUs: eager launches (the step is GPU-bound either way:
+    # 9.0 ms eager vs 9.0 ms replayed at N=1) so that every matrix-gradient bucket is all-reduced over RCCL from a
+    # gradient-ready hook while backward is still running; a captured graph could only start the exchange after it
+    use_graph = not a.no_graph and (world == 1 or a.graph_dp)
     dp = DataParallelStep(model, fusion_step_loss, overlap=not use_graph)
     from hri_emo_amd.optim import FusedClipAdamW
     opt = FusedClipAdamW(dp.buckets, lr=1e-4, weight_decay=1e-2, max_norm=5.0)     # before capture: re-homes the parameters
@@ -263,7 +267,7 @@ def main():
                "config": {"workload": "FusionWithEmotionDecoder fwd+bwd (train mode, dropout 0.1), d=768 T_a=400 "
                                       "T_t=128 N_e=6 H=8, 2 fusion + 2 decoder layers, all-False masks",
                           "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}",
-                          "grad_allreduce": "fp32 flat buckets 32MiB, RCCL" if world > 1 else "none",
+                          "grad_allreduce": ("fp32 flat buckets 32MiB, RCCL, " + ("after the replay" if use_graph else "launched from gradient-ready hooks during backward")) if world > 1 else "none",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "streams": 2 if os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0" else 1},
                "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn,

@@ -73,6 +73,23 @@ def side_stream(device):
     return s
 
 
+_main_streams = {}
+
+
+def note_main_stream(stream):
+    """the stream a fusion block was entered on (its audio branch runs there, the text branch on the side stream)"""
+    _main_streams[stream.device.index] = stream
+
+
+def branch_streams(device):
+    """streams the fusion blocks run on: the main one (as last noted) and the text-branch side stream if it exists"""
+    out = [_main_streams.get(device.index, torch.cuda.current_stream(device))]
+    side = _side_streams.get(device.index)
+    if side is not None:
+        out.append(side)
+    return out
+
+
 def share(t, stream):
     """tensor produced on another stream is about to be read on `stream`"""
     if t is not None:
@@ -152,6 +169,10 @@ class GradSink:
         self.fused = FUSED_WGRAD and all(
             p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
             and p.grad.device == p.device and p.grad.shape == p.shape for p in params)
+        if self.fused:
+            for p in params:
+                if hasattr(p, "_hriemo_grad_ready"):
+                    p._hriemo_sink_managed = True      # dp.GradBuckets: only done() below reports this gradient
 
     def buf(self, p):
         return p.grad if self.fused else torch.empty(p.shape, dtype=torch.float32, device=p.device)
@@ -164,7 +185,10 @@ class GradSink:
             for p in self.params:
                 hook = getattr(p, "_hriemo_grad_ready", None)
                 if hook is not None:
-                    hook(p)
+                    if p.dim() < 2 and DEFER_REDUCE and _in_backward():
+                        _deferred.add_hook(hook, p)       # bias / LayerNorm gradients are final only after the flush
+                    else:
+                        hook(p)
 
 
 def padded_shadow(sh, p, kp):
@@ -324,7 +348,16 @@ class _DeferredReduce:
     on the caller's stream after the engine has joined every stream backward used."""
 
     def __init__(self):
-        self.jobs, self.keep, self.scheduled, self.blocks = [], [], False, 0
+        self.jobs, self.keep, self.scheduled, self.blocks, self.hooks = [], [], False, 0, []
+
+    def _schedule(self):
+        if not self.scheduled:
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            self.scheduled = True
+
+    def add_hook(self, hook, p):
+        self.hooks.append((hook, p))
+        self._schedule()
 
     def add(self, part, pstride, np_, w, nseg, outs, accumulate):
         gx = (w + 31) // 32
@@ -334,9 +367,7 @@ class _DeferredReduce:
         self.keep.append(part)
         self.keep.extend(outs)
         self.device = part.device
-        if not self.scheduled:
-            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
-            self.scheduled = True
+        self._schedule()
 
     def flush(self):
         jobs, n, nblocks = self.jobs, len(self.jobs), self.blocks
@@ -346,11 +377,14 @@ class _DeferredReduce:
             dev = torch.empty((n, 8), dtype=torch.int64, device=self.device)
             _lib.call("hriemo_colreduce_batch", host.data_ptr(), n, _p(dev), nblocks, _stream())
             self.keep.append(dev)
-        if not CAPTURING:           # a captured graph keeps using these buffers on every replay
+        if not CAPTURING and self.keep:     # a captured graph keeps using these buffers on every replay
             cur = torch.cuda.current_stream(self.device)
             for t in self.keep:     # partials of the text branch were allocated on the side stream
                 t.record_stream(cur)
             self.keep = []
+        hooks, self.hooks = self.hooks, []
+        for hook, p in hooks:       # gradient-ready notifications held back until the values are final
+            hook(p)
 
 
 _deferred = _DeferredReduce()

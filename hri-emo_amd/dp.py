@@ -19,7 +19,12 @@ class GradBuckets:
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        order = list(reversed(self.params))
+        # matrices first, in the order backward produces them (decoder first, fusion layer 0 last); every vector
+        # parameter (biases, LayerNorm gain/bias) behind them: their gradients are finished by the launch-boundary
+        # reduce at the END of backward (_ops._DeferredReduce), so they share the last bucket(s) and the matrix
+        # buckets can be all-reduced while backward is still running
+        rev = list(reversed(self.params))
+        order = [p for p in rev if p.dim() >= 2] + [p for p in rev if p.dim() < 2]
         pad = lambda n: (n + 63) // 64 * 64          # every view starts 256-B aligned (16-B vector stores)
         total = sum(pad(p.numel()) for p in order)
         dev = order[0].device
@@ -42,26 +47,43 @@ class GradBuckets:
             self.buckets.append((b_start, off, b_n))
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._reported = set()
         self._works = []
         self._hooks = []
         if overlap and self.world > 1:
-            from . import _ops
-            _ops.DEFER_REDUCE = False        # buckets are all-reduced as soon as their last gradient is written: no deferral
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-                p._hriemo_grad_ready = self._on_grad     # gradients the kernels accumulate in place (_ops.GradSink)
+                p._hriemo_grad_ready = self._on_grad_sink     # gradients the kernels accumulate in place (_ops.GradSink)
 
     # -- hooks ---------------------------------------------------------------------------------
     def _launch(self, bi):
         s, e, _ = self.buckets[bi]
         self._launched[bi] = True
+        if self.flat.is_cuda:
+            # a bucket holds gradients written on both branch streams: the collective is ordered after the launching
+            # (current) stream only, so that stream first waits for the other one
+            from . import _ops
+            cur = torch.cuda.current_stream(self.flat.device)
+            for st in _ops.branch_streams(self.flat.device):
+                if st != cur:
+                    cur.wait_stream(st)
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _on_grad(self, p):
+    def _on_grad(self, p, from_sink=False):
+        """gradient of `p` is final.  Sources: autograd's post-accumulate hook (gradients returned as tensors) and
+        _ops.GradSink (gradients the kernels wrote in place).  While a parameter is sink-managed in this backward pass
+        only the sink's notification counts -- it comes after the producing kernels were issued, for bias / LayerNorm
+        vectors after the launch-boundary reduce -- and every parameter counts once per step."""
+        if (getattr(p, "_hriemo_sink_managed", False) and not from_sink) or id(p) in self._reported:
+            return
+        self._reported.add(id(p))
         bi = self._bucket_of[id(p)]
         self._pending[bi] += 1
         if self._pending[bi] == self.buckets[bi][2] and not self._launched[bi]:
             self._launch(bi)
+
+    def _on_grad_sink(self, p):
+        self._on_grad(p, from_sink=True)
 
     # -- per-step API --------------------------------------------------------------------------
     def _rebind(self):
@@ -85,6 +107,9 @@ class GradBuckets:
             self._works = []
             self._pending = [0] * len(self.buckets)
             self._launched = [False] * len(self.buckets)
+            self._reported = set()
+            for p in self.params:
+                p._hriemo_sink_managed = False
             self.flat.mul_(1.0 / self.world)
 
     def grad_norm(self):

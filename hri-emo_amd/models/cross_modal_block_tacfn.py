@@ -61,6 +61,7 @@ class CrossModalBlock(nn.Module):
         s = self._site
         _ops._require_gpu(a)
         main = torch.cuda.current_stream(a.device)
+        _ops.note_main_stream(main)
         side = _ops.side_stream(a.device)
         if side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81

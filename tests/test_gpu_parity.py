@@ -8,6 +8,8 @@ error is ~2e-3, so the tests hold outputs to |got - ref| <= 5e-3 * max(1, max|re
 gradients: per-parameter relative L2 error bounded by the reference path's own bf16 (autocast) error, see
 test_fusion_train_step_grads.
 """
+import os
+
 import pytest
 import torch
 
@@ -504,3 +506,65 @@ def test_trimmed_batch_gives_the_same_outputs(H):
         trim = m(cu(ta), cu(tt), cu(tma), cu(tmt))
     for a, b, what in zip(full, trim, ("logits", "beta", "z")):
         close(b, a.float().cpu(), what=what)
+
+
+def _dp_overlap_worker(rank, world, port, q):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share GPU 0; gradients cross through the host
+    try:
+        import hri_emo_amd as H
+        from hri_emo_amd.dp import DataParallelStep
+        from hri_emo_amd.train import fusion_step_loss
+        torch.cuda.set_device(0)
+        torch.manual_seed(3)
+        m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+        h_a, h_t, m_a, m_t = _rand_batch(8, 48, 24, 128, 31)
+        y = (torch.rand(8, 4, generator=torch.Generator().manual_seed(5)) < 0.3).float()
+        dp = DataParallelStep(m, fusion_step_loss, bucket_bytes=256 << 10, overlap=True)       # several buckets, hooks on
+        lo, hi = dp.set_global_batch(8)
+        for _ in range(2):
+            dp.step(h_a[lo:hi].cuda().bfloat16(), h_t[lo:hi].cuda().bfloat16(), m_a[lo:hi].cuda(), m_t[lo:hi].cuda(), y[lo:hi].cuda())
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put((dp.buckets.flat.cpu().numpy(), len(dp.buckets.buckets)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_overlapped_allreduce_equals_single_rank(H):
+    """N>1 path as bench.py runs it (eager step, matrix-gradient buckets all-reduced from gradient-ready hooks while
+    backward is still running, bias/LayerNorm bucket after the launch-boundary reduce), rehearsed with two ranks on
+    ONE GPU over gloo: averaged gradients == the single-rank step on the concatenated batch."""
+    import torch.multiprocessing as mp
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat2, nb = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert nb > 2
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(8, 48, 24, 128, 31)
+    y = (torch.rand(8, 4, generator=torch.Generator().manual_seed(5)) < 0.3).float()
+    dp = DataParallelStep(m, fusion_step_loss, bucket_bytes=256 << 10, overlap=False)
+    dp.set_global_batch(8)
+    dp.step(cu(h_a).bfloat16(), cu(h_t).bfloat16(), cu(m_a), cu(m_t), cu(y))
+    ref = dp.buckets.flat.cpu()
+    got = torch.from_numpy(flat2)
+    assert got.shape == ref.shape
+    per_bucket = [(i_, s_, e_, round(_rel(got[s_:e_], ref[s_:e_]), 5)) for i_, (s_, e_, _) in enumerate(dp.buckets.buckets)
+                  if _rel(got[s_:e_], ref[s_:e_]) > 1e-4] + [len(dp.buckets.buckets)]
+    assert _rel(got, ref) < 2e-3, (_rel(got, ref), per_bucket)
+    for (s, e, _) in dp.buckets.buckets:                     # every bucket arrived, none twice
+        assert _rel(got[s:e], ref[s:e]) < 5e-3, (s, e, _rel(got[s:e], ref[s:e]))
