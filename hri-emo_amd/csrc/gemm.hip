@@ -18,6 +18,7 @@
 //    full-line 16-byte stores, fp32 (weight-gradient) tiles as 16-byte stores from registers;
 //  * blockIdx is remapped (bijectively) so each XCD's L2 sees a contiguous range of tiles.
 #include "common.h"
+#include <type_traits>
 
 struct GemmArgs {
   int M, N, K;
@@ -432,6 +433,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
       else if (NS >= 3 && young >= 1) wait_vmcnt<(NS >= 3 ? 1 : 0) * LPT>();
       else wait_vmcnt<0>();
     };
+    // A K-step far enough from the tile's end needs no decisions: the stage it+NS-1 belongs to this tile, stage
+    // it+1 has NS-2 younger groups behind it, and there is a next K-step.  The loops below run that STEADY body for
+    // it < nk-(NS-1) and the general body for the last NS-1 K-steps (stage stream crossing into the next tile).
+    const int n_steady = max(0, nk - (NS - 1));
+    auto prefetch_s = [&](int it, auto steady) {
+      if constexpr (decltype(steady)::value) stage(nxt, T, it + NS - 1);
+      else prefetch(it);
+    };
+    auto retire_s = [&](int it, auto steady) {
+      if constexpr (decltype(steady)::value) wait_vmcnt<(NS - 2) * LPT>();
+      else retire_next(it);
+    };
+    typedef std::integral_constant<bool, true> Steady;
+    typedef std::integral_constant<bool, false> Tail;
     if constexpr (K32) {
       // Staggered two-group schedule (256x256 tile, 32-deep stages).  A SIMD hosts wave w (group 0) and wave
       // w + 4 (group 1).  Every K-step is an S-phase (LDS-DMA issue for stream position it+3, the 12 fragment
@@ -489,8 +504,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
       if constexpr (ILV) {
         // 64x64 wave tiles: two full fragment sets, reads of the next half-step trickle between the MFMAs
         load_frags(smem + cur * STAGE, 0, afA, bfA);
-        for (int it = 0; it < nk; ++it) {
-          prefetch(it);
+        auto kstep = [&](int it, auto steady) {
+          prefetch_s(it, steady);
           __builtin_amdgcn_sched_barrier(0);
           load_frags(smem + cur * STAGE, 1, afB, bfB);
           mma(afA, bfA);
@@ -498,10 +513,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           __builtin_amdgcn_sched_barrier(0);
           cur = (cur + 1 == NS) ? 0 : cur + 1;
           nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-          if (it + 1 < nk) {
+          if (decltype(steady)::value || it + 1 < nk) {
             // stage it+1 must have landed for every wave; our own reads of stage `it` must be retired before
             // any wave may restage that slot (WAR).
-            retire_next(it);
+            retire_s(it, steady);
             __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) alone
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);        // reads + MFMAs in ONE scheduling region
@@ -515,15 +530,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
             mma(afB, bfB);
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        };
+        for (int it = 0; it < n_steady; ++it) kstep(it, Steady());
+        for (int it = n_steady; it < nk; ++it) kstep(it, Tail());
       } else if constexpr (!HALF) {
         // 128x64 wave tile, fp32 output (weight gradients: both operands K-strided, twice the fragment reads, no
         // aux epilogue): two full fragment sets, each 32-deep half-step = two clusters of 16 MFMAs.
         //   DMA | MFMA(A, rows 0..MT/2) | read B-set | MFMA(A, rest) | retire stage it+1 + barrier |
         //   read next A-set | MFMA(B-set)
         load_frags(smem + cur * STAGE, 0, afA, bfA);
-        for (int it = 0; it < nk; ++it) {
-          prefetch(it);
+        auto kstep = [&](int it, auto steady) {
+          prefetch_s(it, steady);
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_setprio(1);
           mma_rows(afA, bfA, 0, MT / 2);
@@ -537,8 +554,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           __builtin_amdgcn_sched_barrier(0);
           cur = (cur + 1 == NS) ? 0 : cur + 1;
           nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-          if (it + 1 < nk) {
-            retire_next(it);
+          if (decltype(steady)::value || it + 1 < nk) {
+            retire_s(it, steady);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
             load_frags(smem + cur * STAGE, 0, afA, bfA);
@@ -550,7 +567,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           mma(afB, bfB);
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        for (int it = 0; it < n_steady; ++it) kstep(it, Steady());
+        for (int it = n_steady; it < nk; ++it) kstep(it, Tail());
       } else {
         // 128x64 wave tile (128 accumulator registers): the A fragments are double-buffered in HALVES (rows
         // 0..63 / 64..127 of the wave tile) and B in two sets, 64 fragment registers instead of 96, so the loop
@@ -584,8 +603,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         };
         load_a(smem + cur * STAGE, 0, 0, a0);
         load_b(smem + cur * STAGE, 0, b0);
-        for (int it = 0; it < nk; ++it) {
-          prefetch(it);
+        auto kstep = [&](int it, auto steady) {
+          prefetch_s(it, steady);
           const char* sa = smem + cur * STAGE;
           __builtin_amdgcn_sched_barrier(0);
           load_a(sa, 0, 1, a1);
@@ -597,8 +616,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
           cluster(0, a0, b1);
           cur = (cur + 1 == NS) ? 0 : cur + 1;
           nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-          if (it + 1 < nk) {
-            retire_next(it);
+          if (decltype(steady)::value || it + 1 < nk) {
+            retire_s(it, steady);
             __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0): a1 is in, slot released
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -606,7 +625,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
             load_b(smem + cur * STAGE, 0, b0);
           }
           cluster(1, a1, b1);
-        }
+        };
+        for (int it = 0; it < n_steady; ++it) kstep(it, Steady());
+        for (int it = n_steady; it < nk; ++it) kstep(it, Tail());
       }
     }
     // This wave's share of the next tile's stage 0 must have landed BEFORE its stores join the queue: loads
