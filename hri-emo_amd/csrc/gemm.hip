@@ -460,10 +460,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
       bf16x8 af[MT], bfr[NTL];
       const bool g1 = STAG && wave >= NWAVE / 2;
       if (g1) __builtin_amdgcn_s_barrier();
-      for (int it = 0; it < nk; ++it) {
-        prefetch(it);
+      auto kstep = [&](int it, auto steady) {
+        prefetch_s(it, steady);
         load_frags(smem + cur * STAGE, 0, af, bfr);
-        retire_next(it);
+        retire_s(it, steady);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): fragments in registers, slot released
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -474,7 +474,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
         if (STAG) __builtin_amdgcn_s_barrier();
         cur = (cur + 1 == NS) ? 0 : cur + 1;
         nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
-      }
+      };
+      for (int it = 0; it < n_steady; ++it) kstep(it, Steady());
+      for (int it = n_steady; it < nk; ++it) kstep(it, Tail());
       if (STAG && !g1) __builtin_amdgcn_s_barrier();
     } else {
     bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
