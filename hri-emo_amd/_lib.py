@@ -35,6 +35,7 @@ _SIGS = {
     "hriemo_add_ln_bwd_partial_rows": ("ii", "i"),
     "hriemo_colsum_partial_rows": ("ii", "i"),
     "hriemo_colreduce_batch": ("pipip", "i"),
+    "hriemo_debug_hog": ("iipp", "i"),
     "hriemo_sumsq_f32": ("plpip", "i"),
     "hriemo_adamw_flat": ("pppplfffffifpp", "i"),
     "hriemo_masked_mean_fwd": ("ppppiiip", "i"),

@@ -18,6 +18,7 @@
 //    full-line 16-byte stores, fp32 (weight-gradient) tiles as 16-byte stores from registers;
 //  * blockIdx is remapped (bijectively) so each XCD's L2 sees a contiguous range of tiles.
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 struct GemmArgs {
@@ -31,6 +32,7 @@ struct GemmArgs {
   int tiles_m, tiles_n, splitk, k_per_split;
   float* ws;
   int accumulate;
+  unsigned* sched;   // per-launch work queue: [0..7] per-XCD next-unit counters, [8] blocks finished; nullptr = static walk
 };
 
 // chunk swizzle of the 64-byte-row image (BK = 32): rows r..r+3 share one 256-B bank row, so the 16-B chunk c of
@@ -341,8 +343,41 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
   const int tiles = p.tiles_m * p.tiles_n;
   const long total = (long)tiles * p.splitk;
   const int end = (int)(total * (before + nx) / G);
-  int wg = (int)(total * before / G) + lb;
-  if (wg >= end) return;
+  const int beg = (int)(total * before / G);
+  // Work queue (p.sched != nullptr): the blocks of an XCD draw that XCD's units from one atomic counter instead of
+  // owning every nx-th one, so a block that gets its CU late (another kernel -- an RCCL collective, the other branch's
+  // GEMM -- is holding it) simply draws fewer units and the launch is not stretched by the blocks that started last.
+  // Ids travel two units ahead: `wg` is being computed, `nwg` is already streaming into the ring, and the id after that
+  // is drawn by lane 0 of wave 0 right before the epilogue (behind the counted wait, so no vmcnt arithmetic changes),
+  // parked in the first word of wave 0's epilogue scratch and read by all waves after the next tile-start barrier.
+  const bool dyn = p.sched != nullptr;
+  unsigned* const qctr = p.sched + xcd;
+  int* const qslot = (int*)(smem + NS * STAGE);          // wave 0's scratch: free between its epilogues
+  auto leave = [&]() {                                    // every block, exactly once, on its way out
+    if (dyn && tid == 0) {
+      const unsigned done = atomicAdd(p.sched + 8, 1u);
+      if (done == gridDim.x - 1) {                        // last one out resets the queue for the next launch
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __hip_atomic_store(p.sched + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  int wg, nwg;
+  if (dyn) {
+    if (tid == 0) {
+      const int first = (int)atomicAdd(qctr, 2u);
+      qslot[0] = beg + first;
+      qslot[1] = beg + first + 1;
+    }
+    __syncthreads();
+    wg = __builtin_amdgcn_readfirstlane(qslot[0]);
+    nwg = __builtin_amdgcn_readfirstlane(qslot[1]);
+    __syncthreads();                                      // both read before anyone's epilogue reuses the scratch
+  } else {
+    wg = beg + lb;
+    nwg = wg + nx;
+  }
+  if (wg >= end) { leave(); return; }
 
   const long astep = TA == 0 ? BK : BK * p.lda, bstep = TB == 0 ? BK : BK * p.ldb;
   const LaneOff aoff = operand_lane<TA, BM, BK>(p.lda, lane), boff = operand_lane<TB, BN, BK>(p.ldb, lane);
@@ -408,8 +443,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
   wait_vmcnt<(NS - 2) * LPT>();
   int cur = 0, nxt = NS - 1;          // ring slots of the stage being computed / being filled
 
+  bool parked = false;                  // wave 0 parked the next-next id in qslot[0] at the end of the last tile
   for (;;) {
-    const int nwg = wg + nx;
+    __builtin_amdgcn_s_barrier();       // stage 0 of this tile (confirmed per wave before its last epilogue) is visible
+    if (parked) nwg = __builtin_amdgcn_readfirstlane(qslot[0]);
     const bool has_next = nwg < end;
     const int nk = T.nk;
     // stream position it+NS-1: issue it if it exists; returns whether a stage group went out.  The next
@@ -420,7 +457,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
       if (has_next) { const TileInfo NX = decode(nwg); stage(nxt, NX, ps - nk); return true; }
       return false;
     };
-    __builtin_amdgcn_s_barrier();       // stage 0 of this tile (confirmed per wave before its last epilogue) is visible
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -635,6 +671,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
     // This wave's share of the next tile's stage 0 must have landed BEFORE its stores join the queue: loads
     // complete in order among themselves, so a counted wait stays exact only while nothing but loads is older.
     if (has_next) wait_vmcnt<(NS - 2) * LPT>();
+    int drawn = end;                    // id of the unit after next (lane 0 of wave 0 only)
+    if (dyn && has_next && tid == 0) drawn = beg + (int)atomicAdd(qctr, 1u);
 #if defined(HRIEMO_GEMM_ABL) && (HRIEMO_GEMM_ABL & 8)
     bool skip_epilogue;                 // timing-only build: no epilogue (stores only on an impossible value)
     {
@@ -661,7 +699,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
     if (!has_next) break;
     T = decode(nwg);
     wg = nwg;
+    if (dyn) {
+      if (tid == 0) qslot[0] = drawn;   // wave 0's epilogue is over: its scratch is free until the next one
+      __builtin_amdgcn_s_waitcnt(0xC07F);          // landed before the tile-start barrier publishes it
+      parked = true;
+    } else {
+      nwg = wg + nx;
+    }
   }
+  leave();
 }
 
 // out[m][n] (+)= sum_s ws[s][m][n]
@@ -704,6 +750,35 @@ extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev
   return 0;
 }
 
+// Work-queue words for the persistent kernels: one 16-word slot per (device, stream) -- launches on one stream are
+// serialised and every launch leaves its slot zeroed (last block out), launches on different streams never share one.
+// Allocated once, outside any stream capture; until then (or with HRIEMO_GEMM_STATIC=1) the kernels walk statically.
+static unsigned* sched_slot(hipStream_t st) {
+  static const bool disabled = [] { const char* e = getenv("HRIEMO_GEMM_STATIC"); return e && e[0] == '1'; }();
+  if (disabled) return nullptr;
+  constexpr int MAXDEV = 16, MAXSLOT = 64;
+  static unsigned* base[MAXDEV] = {nullptr};
+  static hipStream_t owner[MAXDEV][MAXSLOT];
+  static int nslot[MAXDEV] = {0};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (base[dev] == nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    unsigned* b = nullptr;
+    if (hipMalloc(&b, MAXSLOT * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(b, 0, MAXSLOT * 16 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
+    base[dev] = b;
+  }
+  for (int i = 0; i < nslot[dev]; ++i)
+    if (owner[dev][i] == st) return base[dev] + i * 16;
+  if (nslot[dev] == MAXSLOT) return nullptr;
+  owner[dev][nslot[dev]] = st;
+  return base[dev] + (nslot[dev]++) * 16;
+}
+
 template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK = 64>
 static void launch_one(const GemmArgs& a, int ring, hipStream_t st) {
   const int lds = ring + WM * WN * 2048;          // operand ring + 2 KB epilogue scratch per wave
@@ -715,7 +790,9 @@ static void launch_one(const GemmArgs& a, int ring, hipStream_t st) {
   const long units = (long)a.tiles_m * a.tiles_n * a.splitk;
   const long slots = (long)num_cus() * (lds <= 80 * 1024 ? 2 : 1);      // persistent: one block per resident slot
   const int grid = (int)(units < slots ? units : slots);
-  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, BK>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  GemmArgs q = a;
+  q.sched = units > slots ? sched_slot(st) : nullptr;       // a queue only pays when blocks own several units
+  hipLaunchKernelGGL((gemm_kernel<TA, TB, OUTF32, BM, BN, WM, WN, NS, BK>), dim3(grid), dim3(WM * WN * 64), lds, st, q);
 }
 
 template <int TA, int TB, int OUTF32>
@@ -764,7 +841,7 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb;
   a.C = C; a.ldc = ldc; a.bias = bias; a.aux = (const bf16_t*)aux; a.ldaux = ldaux; a.epi = epilogue;
   a.tiles_m = (M + kCfg[cfg].bm - 1) / kCfg[cfg].bm; a.tiles_n = (N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
-  a.ws = workspace; a.accumulate = accumulate;
+  a.ws = workspace; a.accumulate = accumulate; a.sched = nullptr;
   int splitk = 1;
   if (c_is_f32) {
     const long tiles = (long)a.tiles_m * a.tiles_n;

@@ -82,3 +82,22 @@ extern "C" int hriemo_prof_collect(int cls, double* ms_total, long* launches, do
   *work = c.work;
   return 0;
 }
+
+
+// Tuning hook: occupy `blocks` CUs for about `micros` microseconds (one 100 KB-LDS block each, so nothing else fits
+// beside it) -- stands in for a collective holding CUs while the persistent kernels run (scripts_dev/bench_hog.py).
+__global__ __launch_bounds__(64) void hog_kernel(long ticks, float* sink) {
+  extern __shared__ char hog_lds[];
+  hog_lds[threadIdx.x] = 1;
+  const long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (hog_lds[threadIdx.x] == 77) sink[0] = 1.f;
+}
+extern "C" int hriemo_debug_hog(int blocks, int micros, float* sink, hipStream_t st) {
+  HRIEMO_CHECK(blocks > 0 && blocks <= 256 && micros > 0 && micros <= 100000 && sink != nullptr, "debug_hog: bad arguments");
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); attr = true; }
+  hipLaunchKernelGGL(hog_kernel, dim3(blocks), dim3(64), 100 * 1024, st, (long)micros * 100, sink);   // 100 MHz clock
+  HRIEMO_LAUNCH_CHECK("hog_kernel");
+  return 0;
+}
