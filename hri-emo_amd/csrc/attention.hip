@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
   const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
   const int nkt = (a.Lk + 63) >> 6;
 
-  constexpr bool PF = (NW == 4) && (HD <= 96);     // hd=128 has no registers left for the staging set
+  constexpr bool PF = (NW == 4);
   TileRegs<HD, 64, NT> kr, vr;
   if (PF) {
     tile_fetch<HD, 64, NT>(kr, Kb, a.ldk, 0, a.Lk, tid);
