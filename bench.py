@@ -159,6 +159,27 @@ def main():
     value = B * world / (ms * 1e-3)
     log(f"{ms:.3f} ms/step -> {value:.1f} utt/s (host enqueue {host_ms:.3f} ms/step)")
 
+    # secondary number: the same step with ragged key-padding masks, valid length ~U[0.5 L, L] per sample and
+    # modality.  PAD keys are masked, PAD query rows are still computed (as in the reference), so this mainly shows that
+    # masks cost nothing; hri_emo_amd.data.trim_padding / length_bucketed_batches are what remove the padding itself.
+    ragged = None
+    if rank == 0 and world == 1 and not a.no_roofline:
+        g = torch.Generator().manual_seed(4321)
+        la = torch.randint(T_A // 2, T_A + 1, (B,), generator=g)
+        lt = torch.randint(T_T // 2, T_T + 1, (B,), generator=g)
+        rb = (batch[0], batch[1], (torch.arange(T_A)[None] >= la[:, None]).to(device), (torch.arange(T_T)[None] >= lt[:, None]).to(device), batch[4])
+        for _ in range(3):
+            dp.step(*rb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dp.step(*rb)
+        torch.cuda.synchronize()
+        rms = (time.perf_counter() - t1) / 10 * 1e3
+        ragged = {"ms_per_step": round(rms, 3), "value": round(B / (rms * 1e-3), 1), "valid_fraction": round(float((la.sum() / T_A + lt.sum() / T_T) / (2 * B)), 3)}
+        log(f"ragged masks: {rms:.3f} ms/step")
+        dp.step(*batch)                              # gradients of the headline batch again for the legs below
+
     # optimizer step, timed separately: the trainer's clip_grad_norm_(5.0) + AdamW(lr 1e-4, wd 1e-2) on the
     # flat fp32 parameter buffer with the gradients of the last step (train_fusion_seq_level_decoder.py:332-334).
     # Never in `value`.
@@ -270,7 +291,7 @@ def main():
                           "grad_allreduce": ("fp32 flat buckets 32MiB, RCCL, " + ("after the replay" if use_graph else "launched from gradient-ready hooks during backward")) if world > 1 else "none",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "streams": 2 if os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0" else 1},
-               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn,
+               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn, "ragged_masks": ragged,
                "model_tflops": round(value * FLOP_PER_UTT_FWD_BWD / 1e12, 1),
                "model_mfma_frac": round(value * FLOP_PER_UTT_FWD_BWD / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
         if roof is not None:
