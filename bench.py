@@ -276,7 +276,13 @@ def main():
                 "algorithmic_flop_per_launch": round(work / max(n, 1)),
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": n // nprof,
                 "timing": "HIP events around each launch, 5 eager steps, single stream (kernels not overlapped)",
-                "device_ms_per_step_by_class": {r[0]: round(r[1] / nprof, 3) for r in rows}}
+                "device_ms_per_step_by_class": {r[0]: round(r[1] / nprof, 3) for r in rows},
+                # every class against its own bound: MFMA classes in TFLOP/s of algorithmic FLOPs over the dense bf16
+                # peak, the row kernels in GB/s of algorithmic bytes over HBM (8 TB/s)
+                "achieved_by_class": {r[0]: ({"achieved": round(r[3] / (r[1] * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(r[3] / (r[1] * 1e-3) / 8e12, 4)}
+                                             if r[0] == "rowops" else
+                                             {"achieved": round(r[3] / (r[1] * 1e-3) / 1e12, 1), "unit": "TFLOP/s", "frac": round(r[3] / (r[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)})
+                                      for r in rows if r[1] > 0}}
     if world > 1:
         dist.barrier()
 
