@@ -249,8 +249,10 @@ def main():
         _ops.TWO_STREAMS = False          # time each kernel ALONE: with the text branch on a second stream the
         L.hriemo_prof_enable(1)           # event pairs would also count the time a kernel shares the chip
         nprof = min(a.steps, 5)
+        dp.buckets.suspended = True                     # rank-local steps: no gradient exchange may be launched
         for _ in range(nprof):                          # instrumented steps run eagerly (events per launch)
             dp._fwd_bwd(*batch)
+        dp.buckets.suspended = False
         torch.cuda.synchronize()
         rows = []
         for c in range(L.hriemo_prof_nclass()):

@@ -48,6 +48,7 @@ class GradBuckets:
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._reported = set()
+        self.suspended = False      # True: gradient-ready notifications are ignored (rank-local diagnostic steps: no collectives)
         self._works = []
         self._hooks = []
         if overlap and self.world > 1:
@@ -74,7 +75,7 @@ class GradBuckets:
         _ops.GradSink (gradients the kernels wrote in place).  While a parameter is sink-managed in this backward pass
         only the sink's notification counts -- it comes after the producing kernels were issued, for bias / LayerNorm
         vectors after the launch-boundary reduce -- and every parameter counts once per step."""
-        if (getattr(p, "_hriemo_sink_managed", False) and not from_sink) or id(p) in self._reported:
+        if self.suspended or (getattr(p, "_hriemo_sink_managed", False) and not from_sink) or id(p) in self._reported:
             return
         self._reported.add(id(p))
         bi = self._bucket_of[id(p)]

@@ -568,3 +568,22 @@ def test_two_ranks_overlapped_allreduce_equals_single_rank(H):
     assert _rel(got, ref) < 2e-3, (_rel(got, ref), per_bucket)
     for (s, e, _) in dp.buckets.buckets:                     # every bucket arrived, none twice
         assert _rel(got[s:e], ref[s:e]) < 5e-3, (s, e, _rel(got[s:e], ref[s:e]))
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py exactly as the driver launches it for N>1 (torch.distributed.run, one rank per GPU), rehearsed with both
+    ranks on this box's single GPU over gloo (HRIEMO_DIST_BACKEND): every leg must run to the one JSON line on rank 0
+    without a rank-local step launching a collective the other rank never joins."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HRIEMO_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 100), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch-per-gpu", "8"]
+    r = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["launch"] == "eager" and d["value"] > 0
+    assert "roofline" in d and d["roofline"]["frac"] > 0 and d["cross_attention"] is not None
