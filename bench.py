@@ -122,6 +122,9 @@ def main():
     # one GPU: the whole step is one hipGraph replay.  Several GPUs: eager launches (the step is GPU-bound either way:
     # 9.0 ms eager vs 9.0 ms replayed at N=1) so that every matrix-gradient bucket is all-reduced over RCCL from a
     # gradient-ready hook while backward is still running; a captured graph could only start the exchange after it
+    # N>1 without a forced mode: both are warmed up and the faster one (max over ranks) runs the timed region -- eager
+    # overlap wins unless the host cannot keep the launches ahead of the GPU, the replay is immune to that.
+    auto_mode = world > 1 and not a.no_graph and not a.graph_dp
     use_graph = not a.no_graph and (world == 1 or a.graph_dp)
     dp = DataParallelStep(model, fusion_step_loss, overlap=not use_graph)
     from hri_emo_amd.optim import FusedClipAdamW
@@ -141,6 +144,26 @@ def main():
     if use_graph:
         dp.capture(*batch)
         log("step captured into a hipGraph (zero-grad + fwd + loss + bwd)")
+    if auto_mode:
+        def probe(n=3):
+            dp.step(*batch)
+            sync()
+            t = time.perf_counter()
+            for _ in range(n):
+                dp.step(*batch)
+            sync()
+            tt = torch.tensor([(time.perf_counter() - t) / n], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return tt.item()
+        t_eager = probe()
+        dp.buckets.suspended = True
+        dp.capture(*batch)
+        dp.use_graph(True)
+        t_graph = probe()
+        use_graph = t_graph < t_eager
+        dp.use_graph(use_graph)
+        log(f"N={world}: eager + overlapped exchange {t_eager * 1e3:.3f} ms/step, replay + exchange after {t_graph * 1e3:.3f} ms/step -> "
+            f"{'replay' if use_graph else 'eager'}")
     for _ in range(a.warmup):
         dp.step(*batch)
     sync()

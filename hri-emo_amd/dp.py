@@ -160,8 +160,8 @@ class DataParallelStep:
     def capture(self, h_a, h_t, m_a, m_t, y):
         """Record one step on static copies of the batch tensors; later ``step()`` calls replay it."""
         from . import _ops
-        if self.buckets._hooks:
-            raise RuntimeError("capture() needs GradBuckets(overlap=False): collectives are not captured")
+        if self.buckets._hooks and not self.buckets.suspended:
+            raise RuntimeError("capture() needs GradBuckets(overlap=False) or buckets.suspended = True: collectives are not captured")
         self._static = [None if t is None else t.clone() for t in (h_a, h_t, m_a, m_t, y)]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -180,9 +180,16 @@ class DataParallelStep:
         finally:
             _ops.CAPTURING = False
         self._graph = graph
+        self._replay = True
+
+    def use_graph(self, on):
+        """Switch between the captured replay (gradient exchange after it) and eager launches (exchange from the
+        gradient-ready hooks during backward, if installed)."""
+        self._replay = bool(on) and self._graph is not None
+        self.buckets.suspended = self._replay
 
     def step(self, h_a, h_t, m_a, m_t, y):
-        if self._graph is not None:
+        if self._graph is not None and getattr(self, "_replay", True):
             for s, t in zip(self._static, (h_a, h_t, m_a, m_t, y)):
                 if s is not None and t is not None and s.data_ptr() != t.data_ptr():
                     s.copy_(t)
