@@ -281,11 +281,27 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
+def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None):
+    """bias_grad = (db_q [d], db_kv [2d]) fp32 views to ACCUMULATE the column sums of dQ and dK|dV into: the kernels
+    leave per-wave partial sums behind and the launch-boundary reduce adds them up (no pass over dQ/dK/dV).
+    Returns True if it took care of them."""
     delta = torch.empty_like(lse)
+    pq = pkv = None
+    fold = bias_grad is not None and DEFER_REDUCE and FOLD_ATTN_BIAS and _in_backward()
+    if fold:
+        L_ = _lib.lib()
+        rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, Lq), L_.hriemo_attn_bwd_colsum_rows(B, Lk)
+        pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
+        pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
     _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
               _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
-              _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _stream())
+              _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
+              _p(pq), _p(pkv), _stream())
+    if fold:
+        d = H * hd
+        _deferred.add(pq, d, rq, d, 1, [bias_grad[0]], True)
+        _deferred.add(pkv, 2 * d, rk, 2 * d, 1, [bias_grad[1]], True)
+    return fold
 
 
 def attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off):
@@ -339,6 +355,7 @@ TWIN = _os.environ.get("HRIEMO_FP32_TWIN", "1") != "0"      # carry the fp32 twi
 
 
 DEFER_REDUCE = _os.environ.get("HRIEMO_DEFER_REDUCE", "1") != "0"
+FOLD_ATTN_BIAS = _os.environ.get("HRIEMO_FOLD_ATTN_BIAS", "1") != "0"   # in-proj bias grads from the attention backward kernels
 
 
 class _DeferredReduce:
@@ -474,12 +491,13 @@ class SelfAttnLN(torch.autograd.Function):
         linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
         dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
-        attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                 lse, B, H, L, L, hd, kpm, p, seed, site, b_off)
+        db_in = sink.buf(p_b_in)
+        folded = attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
+                          lse, B, H, L, L, hd, kpm, p, seed, site, b_off, bias_grad=(db_in[:d], db_in[d:]) if acc else None)
         dw_in = sink.buf(p_w_in)
         linear_dw(dqkv, x2, dw_in, acc)
-        db_in = sink.buf(p_b_in)
-        colsum(dqkv, db_in, acc)
+        if not folded:
+            colsum(dqkv, db_in, acc)
         dx = linear_dx(dqkv, w_in16, epi=3, aux=ds)
         sink.done()
         r = sink.ret
@@ -531,14 +549,15 @@ class CrossAttnLN(torch.autograd.Function):
         do = linear_dx(dg, w_out16)
         dq = torch.empty((B * Lq, d), dtype=BF16, device=dev)
         dkv = torch.empty((B * Lk, 2 * d), dtype=BF16, device=dev)
-        attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm, p, seed,
-                 site, b_off)
+        db_in = sink.buf(p_b_in)
+        folded = attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm, p, seed,
+                          site, b_off, bias_grad=(db_in[:d], db_in[d:]) if acc else None)
         dw_in = sink.buf(p_w_in)
         linear_dw(dq, xq2, dw_in[:d], acc)
         linear_dw(dkv, xkv2, dw_in[d:], acc)
-        db_in = sink.buf(p_b_in)
-        colsum(dq, db_in[:d], acc)
-        colsum(dkv, db_in[d:], acc)
+        if not folded:
+            colsum(dq, db_in[:d], acc)
+            colsum(dkv, db_in[d:], acc)
         dxq = linear_dx(dq, w_in16[:d], epi=3, aux=ds)
         dxkv = linear_dx(dkv, w_in16[d:])
         sink.done()

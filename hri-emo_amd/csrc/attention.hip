@@ -31,6 +31,8 @@ struct AttnArgs {
   float* lse;
   float* delta;
   float* probs;        // [B, Lq, Lk] head-averaged probabilities (export kernel only)
+  float* csq;          // optional per-block column sums of the dQ tiles  [B*tiles_q, H*HD]      (in-proj bias gradient)
+  float* cskv;         // optional per-block column sums of the dK | dV tiles [B*tiles_k, 2*H*HD]
   int B, H, Lq, Lk;
   float scale;
   uint32_t thr16; float inv_keep; uint64_t seed; uint32_t site; int b_offset;
@@ -321,6 +323,32 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// Column sums of a block's output tile (bias gradients of the packed in-projection): a lane holds columns
+// dt*16 + 4g .. +3 of row i of every 16-row sub-tile.  Sum over the 16 lanes of a row group, then over the waves through
+// LDS (free by now: the caller has passed a barrier after its last tile), one fp32 row of HD columns per block.
+__device__ __forceinline__ int gridDim_tiles(int L, int rows_per_block) { return (L + rows_per_block - 1) / rows_per_block; }
+template <int DT, int NW>
+__device__ __forceinline__ void block_colsum_store(f32x4 (&cs)[DT], float* red, float* dst, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    f32x4 v = cs[dt];
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], m, 64);
+    }
+    if ((lane & 15) == 0) *(f32x4*)(red + wave * (DT * 16) + dt * 16 + 4 * (lane >> 4)) = v;
+  }
+  __syncthreads();
+  for (int c = tid; c < DT * 16; c += NW * 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w * (DT * 16) + c];
+    dst[c] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ dQ (+ delta)
 template <int HD, int NW, int QW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) {
@@ -470,6 +498,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
       }
     }
   }
+  f32x4 cs[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) cs[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int qs = 0; qs < QW; ++qs) {
     const int q = qbase + qs * 16 + i;
@@ -479,9 +510,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
     for (int dt = 0; dt < DT; ++dt) {
       bf16x4 w;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(dq[qs][dt][r] * a.scale);
+      for (int r = 0; r < 4; ++r) {
+        w[r] = (bf16_t)(dq[qs][dt][r] * a.scale);
+        cs[dt][r] += (float)w[r];                 // the stored (rounded) values: what a column sum of dQ would read
+      }
       *(bf16x4*)(dqp + dt * 16) = w;
     }
+  }
+  if (a.csq != nullptr) {          // kernel-uniform
+    __syncthreads();                // every wave is done with the K/V tiles
+    block_colsum_store<DT, NW>(cs, (float*)lds, a.csq + (long)(b * gridDim_tiles(a.Lq, NW * QW * 16) + tile) * ((long)a.H * HD) + h * HD, tid);
   }
 }
 
@@ -634,6 +672,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
       }
     __syncthreads();
   }
+  f32x4 csk[DT], csv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { csk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; csv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw) {
     const int key = kbase + kw * 16 + i;
@@ -647,10 +688,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
       for (int r = 0; r < 4; ++r) {
         wk[r] = (bf16_t)(dk[kw][dt][r] * a.scale);
         wv[r] = (bf16_t)dv[kw][dt][r];
+        csk[dt][r] += (float)wk[r];
+        csv[dt][r] += (float)wv[r];
       }
       *(bf16x4*)(dkp + dt * 16) = wk;
       *(bf16x4*)(dvp + dt * 16) = wv;
     }
+  }
+  if (a.cskv != nullptr) {         // kernel-uniform
+    float* row = a.cskv + (long)(b * gridDim_tiles(a.Lk, NW * KW * 16) + tile) * (2L * a.H * HD) + h * HD;
+    __syncthreads();
+    block_colsum_store<DT, NW>(csk, (float*)lds, row, tid);
+    block_colsum_store<DT, NW>(csv, (float*)lds + NW * DT * 16, row + (long)a.H * HD, tid);
   }
 }
 
@@ -771,15 +820,24 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   return 0;
 }
 
+// rows of the per-wave column-sum partials hriemo_attn_bwd writes for a sequence of length L on the row side of its
+// dQ (L = Lq) or dK/dV (L = Lk) kernel: B * blocks-per-(b,h), the launch geometry chosen below
+extern "C" int hriemo_attn_bwd_colsum_rows(int B, int L) {
+  if (L > 64 && attn_wide(1)) return B * ((L + 127) / 128);
+  if (L > 16) return B * ((L + 63) / 64);
+  return B;
+}
+
 extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                                const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
                                long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
                                const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
                                float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
-                               hipStream_t st) {
+                               float* dq_colsum_partials, float* dkv_colsum_partials, hipStream_t st) {
   AttnArgs a = {};
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.csq = dq_colsum_partials; a.cskv = dkv_colsum_partials;
   a.dO = (const bf16_t*)dO; a.lddo = lddo;
   a.dQ = (bf16_t*)dQ; a.dK = (bf16_t*)dK; a.dV = (bf16_t*)dV; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.kpm = key_padding_mask; a.lse = (float*)lse; a.delta = delta; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;

@@ -60,7 +60,14 @@ int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void
                     const void* dO, long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
                     const unsigned char* key_padding_mask, const float* lse, float* delta, int B, int H, int Lq,
                     int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
-                    unsigned site, int b_offset, hriemo_stream_t stream);
+                    unsigned site, int b_offset, float* dq_colsum_partials, float* dkv_colsum_partials,
+                    hriemo_stream_t stream);
+/* Optional by-product of hriemo_attn_bwd (either pointer may be NULL): per-block column sums of the stored dQ tiles,
+ * [hriemo_attn_bwd_colsum_rows(B, Lq), H*head_dim] fp32, and of the stored dK | dV tiles,
+ * [hriemo_attn_bwd_colsum_rows(B, Lk), 2*H*head_dim] fp32.  Summed over rows (hriemo_colreduce_batch) they are the
+ * gradient of the packed in-projection bias (in_proj_bias of nn.MultiheadAttention, cross_modal_block_tacfn.py:24-40)
+ * without re-reading dQ/dK/dV. */
+int hriemo_attn_bwd_colsum_rows(int B, int L);
 /* head-averaged attention probabilities [B,Lq,Lk] fp32 (need_weights=True; return_attention path,
  * cross_modal_block_tacfn.py:70-125, emotion_decoder.py:48-64) */
 int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,

@@ -185,6 +185,28 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
         err = (got.float().cpu() - ref).abs().max().item()
         assert err <= 3e-2 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
 
+    # by-product: per-block column sums of the stored dQ and dK|dV (in-projection bias gradient) through the C-ABI
+    from hri_emo_amd import _lib
+    L_ = _lib.lib()
+    rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, Lq), L_.hriemo_attn_bwd_colsum_rows(B, Lk)
+    pq = torch.full((rq, d), float("nan"), device="cuda")
+    pkv = torch.full((rk, 2 * d), float("nan"), device="cuda")
+    dq2, dkv2 = torch.empty_like(qd), torch.empty_like(kvd)
+    delta = torch.empty_like(lse)
+    k_, v_ = kvd[:, :d], kvd[:, d:]
+    _lib.call("hriemo_attn_bwd", qd.data_ptr(), qd.stride(0), k_.data_ptr(), k_.stride(0), v_.data_ptr(), v_.stride(0),
+              o.data_ptr(), o.stride(0), dod.data_ptr(), dod.stride(0), dq2.data_ptr(), dq2.stride(0),
+              dkv2[:, :d].data_ptr(), dkv2.stride(0), dkv2[:, d:].data_ptr(), dkv2.stride(0),
+              kpm_d.data_ptr() if kpm_d is not None else None, lse.data_ptr(), delta.data_ptr(), B, H, Lq, Lk, hd, float(p),
+              seed, ops.seed_word(qd.device).data_ptr(), site, boff, pq.data_ptr(), pkv.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv)
+    for name, part, full in (("dq", pq, dq), ("dkv", pkv, dkv)):
+        ref = full.float().sum(0).cpu()
+        got = part.sum(0).cpu()
+        assert not torch.isnan(part).any(), name       # every partial row is written
+        assert (got - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), (name, (got - ref).abs().max())
+
 
 def test_attention_all_pad_row_is_nan(ops):
     B, H, L, hd = 2, 2, 8, 16
