@@ -35,7 +35,7 @@ shapes_nn = [(384, 768, 2304), (384, 2048, 768), (384, 768, 2048), (25600, 768, 
 shapes_tn = [(3072, 768, 25600), (768, 3072, 25600), (768, 768, 25600), (2304, 768, 25600), (768, 768, 8192), (3072, 768, 8192)]      # (Nout, Kout, Mred)
 torch.manual_seed(0)
 res = {}
-ncfg = int(os.environ.get("NCFG", "5"))
+ncfg = int(os.environ.get("NCFG", "6"))
 for cfg in range(ncfg):
     ok, info = check(cfg)
     print(f"cfg {cfg}: exact={ok} {info or ''}", flush=True)

@@ -72,7 +72,7 @@ def test_gemm_tn_exact_splitk(ops, M, N, K):
     assert torch.equal(big[8:].cpu(), ref) and float(big[:8].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_gemm_every_tile_config_and_persistent_walk(ops, cfg):
     """Each tile configuration forced in turn: ragged edges, every epilogue, and a problem with more tiles than
     resident blocks so the persistent walk (next-tile prefetch, private epilogue scratch) is exercised."""
