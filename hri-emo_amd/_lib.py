@@ -15,7 +15,7 @@ _SIGS = {
     "hriemo_gemm_force_config": ("i", "i"),
     "hriemo_attn_fwd": ("plplplplppiiiiifQpIip", "i"),
     "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIippp", "i"),
-    "hriemo_attn_bwd_colsum_rows": ("ii", "i"),
+    "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),

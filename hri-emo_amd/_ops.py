@@ -290,7 +290,7 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
     fold = bias_grad is not None and DEFER_REDUCE and FOLD_ATTN_BIAS and _in_backward()
     if fold:
         L_ = _lib.lib()
-        rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, Lq), L_.hriemo_attn_bwd_colsum_rows(B, Lk)
+        rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, H, Lq, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
         pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
         pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
     _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),

@@ -822,8 +822,32 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
 
 // rows of the per-wave column-sum partials hriemo_attn_bwd writes for a sequence of length L on the row side of its
 // dQ (L = Lq) or dK/dV (L = Lk) kernel: B * blocks-per-(b,h), the launch geometry chosen below
-extern "C" int hriemo_attn_bwd_colsum_rows(int B, int L) {
-  if (L > 64 && attn_wide(1)) return B * ((L + 127) / 128);
+// Backward tile width for a row side of length L (queries for dQ, keys for dK/dV).  Narrow blocks (64 rows, ~160
+// VGPRs, 3 per CU) win in general; but their blocks live as long as the whole key / query loop, so a grid that fills
+// the chip 1.33 times (B*H = 512, L = 128: 1024 blocks on 768 slots) runs a second, mostly empty round.  The wide tile
+// (128 rows, 2 blocks per CU) is picked when it fills its slots >= 90 % and the narrow one < 75 %
+// (scripts_dev/bench_attn_split.py: dK/dV at L_k = 128 51.0 vs 60.5 us, dQ at L_q = 128 39.8 vs 43.5 us).
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+static bool bwd_wide(int L, int BH, int head_dim) {
+  if (L <= 64) return false;
+  if (attn_wide(1)) return true;
+  if (head_dim > 96) return false;                       // register budgets above were measured for hd <= 96
+  const long sn = 3L * cu_count(), sw = 2L * cu_count();
+  const long nn = (long)((L + 63) / 64) * BH, nw = (long)((L + 127) / 128) * BH;
+  const double en = (double)nn / (double)(((nn + sn - 1) / sn) * sn), ew = (double)nw / (double)(((nw + sw - 1) / sw) * sw);
+  return en < 0.75 && ew >= 0.9;
+}
+
+extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {
+  if (bwd_wide(L, B * H, head_dim)) return B * ((L + 127) / 128);
   if (L > 16) return B * ((L + 63) / 64);
   return B;
 }
@@ -848,7 +872,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
                    ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0, "attn_bwd: unaligned operand");
   hriemo_prof_begin(HP_ATTN_BWD_DQ, st);
-  if (Lq > 64 && attn_wide(1)) {
+  if (bwd_wide(Lq, B * H, head_dim)) {
 #define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
@@ -864,7 +888,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_LAUNCH_CHECK("attn_bwd_dq_kernel");
   hriemo_prof_end(HP_ATTN_BWD_DQ, st, 6.0 * B * H * (double)Lq * Lk * head_dim);
   hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
-  if (Lk > 64 && attn_wide(1)) {
+  if (bwd_wide(Lk, B * H, head_dim)) {
 #define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL

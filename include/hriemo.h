@@ -63,11 +63,11 @@ int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void
                     unsigned site, int b_offset, float* dq_colsum_partials, float* dkv_colsum_partials,
                     hriemo_stream_t stream);
 /* Optional by-product of hriemo_attn_bwd (either pointer may be NULL): per-block column sums of the stored dQ tiles,
- * [hriemo_attn_bwd_colsum_rows(B, Lq), H*head_dim] fp32, and of the stored dK | dV tiles,
- * [hriemo_attn_bwd_colsum_rows(B, Lk), 2*H*head_dim] fp32.  Summed over rows (hriemo_colreduce_batch) they are the
+ * [hriemo_attn_bwd_colsum_rows(B, H, Lq, head_dim), H*head_dim] fp32, and of the stored dK | dV tiles,
+ * [hriemo_attn_bwd_colsum_rows(B, H, Lk, head_dim), 2*H*head_dim] fp32.  Summed over rows (hriemo_colreduce_batch) they are the
  * gradient of the packed in-projection bias (in_proj_bias of nn.MultiheadAttention, cross_modal_block_tacfn.py:24-40)
  * without re-reading dQ/dK/dV. */
-int hriemo_attn_bwd_colsum_rows(int B, int L);
+int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim);
 /* head-averaged attention probabilities [B,Lq,Lk] fp32 (need_weights=True; return_attention path,
  * cross_modal_block_tacfn.py:70-125, emotion_decoder.py:48-64) */
 int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,

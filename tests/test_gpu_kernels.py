@@ -136,6 +136,7 @@ ATTN_CASES = [  # B, H, Lq, Lk, hd, masked, p
     (3, 8, 32, 16, 16, True, 0.1),
     (1, 2, 200, 200, 128, False, 0.0),
     (1, 4, 50, 1000, 32, True, 0.0),
+    (64, 8, 128, 70, 96, True, 0.1),      # B*H = 512 at L <= 128: the backward picks its 128-row tiles (one round of blocks)
 ]
 
 
@@ -188,7 +189,7 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
     # by-product: per-block column sums of the stored dQ and dK|dV (in-projection bias gradient) through the C-ABI
     from hri_emo_amd import _lib
     L_ = _lib.lib()
-    rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, Lq), L_.hriemo_attn_bwd_colsum_rows(B, Lk)
+    rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, H, Lq, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
     pq = torch.full((rq, d), float("nan"), device="cuda")
     pkv = torch.full((rk, 2 * d), float("nan"), device="cuda")
     dq2, dkv2 = torch.empty_like(qd), torch.empty_like(kvd)
