@@ -99,3 +99,27 @@ for t, dlt, n, b in ev:
 print(f"time with ONE kernel in flight, per step, by kernel (max blocks); with < 256 blocks: {alone_small / NSTEP / 1e6:.3f} ms/step")
 for k, (t, b) in sorted(alone.items(), key=lambda kv: -kv[1][0])[:24]:
     print(f"  {t / NSTEP / 1e6:7.3f} ms  blocks<={b:6d}  {k}")
+
+# per-stream busy time (a stream's kernels never overlap each other)
+busy = defaultdict(int)
+cnt = defaultdict(int)
+for n, s_, e, q in win:
+    busy[q] += e - s_
+    cnt[q] += 1
+print("per-stream busy time per step:")
+for q in sorted(busy):
+    print(f"  stream {q}: {busy[q] / NSTEP / 1e6:.3f} ms in {cnt[q] / NSTEP:.0f} dispatches")
+# main-stream stalls: gaps on the busiest stream while the other stream is running (waiting at a join)
+main = max(busy, key=busy.get)
+mk = sorted([r for r in win if r[3] == main], key=lambda r: r[1])
+stall = 0
+big = []
+for a, b in zip(mk, mk[1:]):
+    g = b[1] - a[2]
+    if g > 3000:
+        stall += g
+        big.append((g, a[0], b[0]))
+big.sort(reverse=True)
+print(f"gaps > 3 us on stream {main}: {stall / NSTEP / 1e6:.3f} ms/step; largest:")
+for g, a, b in big[:12]:
+    print(f"  {g / 1e3:7.1f} us  {short(a)} -> {short(b)}")
