@@ -802,7 +802,10 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   if (check_common(a, head_dim)) return 1;
   HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: unaligned O");
   hriemo_prof_begin(HP_ATTN_FWD, st);
-  if (Lq > 64 && attn_wide(0)) {
+  // two 16-row query sub-tiles per wave (K/V fragment reuse) unless the key loop is short and the 128-row tiles pad the
+  // query side visibly more than 64-row tiles do (L_q = 400, L_k = 128: 512 vs 448 rows, 44.3 vs 40.5 us)
+  const bool short_keys_padded = Lk <= 128 && ((Lq + 63) / 64) * 64 * 20 < ((Lq + 127) / 128) * 128 * 19;
+  if (Lq > 64 && attn_wide(0) && !short_keys_padded) {
 #define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 2>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL

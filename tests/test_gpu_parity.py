@@ -187,8 +187,8 @@ def _rand_batch(B, Ta, Tt, d, seed, ragged=True):
     h_a, h_t = torch.randn(B, Ta, d, generator=g), torch.randn(B, Tt, d, generator=g)
     if not ragged:
         return h_a, h_t, None, None
-    la = torch.randint(Ta // 2, Ta + 1, (B,), generator=g)
-    lt = torch.randint(Tt // 2, Tt + 1, (B,), generator=g)
+    la = torch.randint(max(1, Ta // 2), Ta + 1, (B,), generator=g)
+    lt = torch.randint(max(1, Tt // 2), Tt + 1, (B,), generator=g)
     return h_a, h_t, torch.arange(Ta)[None] >= la[:, None], torch.arange(Tt)[None] >= lt[:, None]
 
 
@@ -197,6 +197,8 @@ def _rand_batch(B, Ta, Tt, d, seed, ragged=True):
     (2, 1000, 50, 768, 6, 2, 2),          # BASELINE configs[3]: MOSEI shape, long asymmetric cross-attention
     (2, 400, 128, 1024, 7, 4, 2),         # BASELINE configs[4] dimensions (d=1024 -> head_dim 128, 4+2 layers), bf16 path
     (2, 64, 64, 512, 5, 1, 1),            # L_a == L_t (no truncation in the gate), head_dim 64, 1+1 layers
+    (1, 1, 1, 128, 1, 1, 1),              # one utterance, one frame, one token, one emotion query
+    (3, 17, 5, 128, 3, 2, 2), (5, 33, 7, 256, 2, 1, 2),     # odd lengths
 ])
 def test_fusion_vs_oracle_seeded(H, B, Ta, Tt, d, ne, lf, ld):
     torch.manual_seed(1234)
@@ -210,6 +212,19 @@ def test_fusion_vs_oracle_seeded(H, B, Ta, Tt, d, ne, lf, ld):
         lr, br, zr = ref(h_a, h_t, m_a, m_t)
         lg, bg, zg = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
     close(lg, lr, what="logits"); close(bg, br, what="beta"); close(zg, zr, what="z")
+
+
+def test_text_longer_than_audio_raises_like_the_reference(H):
+    """The gate aligns both streams to the text length (beta_gate_tacfn.py:98-116): with L_t > L_a the reference fails
+    with a RuntimeError (shape mismatch); the drop-in refuses the same input with the same exception type."""
+    kw = dict(d_model=128, num_emotions=2, n_heads=8, dropout=0.0, num_layers_fusion=1, num_layers_decoder=1)
+    ref, m = O.FusionWithEmotionDecoder(**kw).eval(), H.FusionWithEmotionDecoder(**kw).cuda().eval()
+    h_a, h_t, _, _ = _rand_batch(2, 7, 33, 128, 3, ragged=False)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            ref(h_a, h_t)
+        with pytest.raises(RuntimeError):
+            m(cu(h_a), cu(h_t))
 
 
 def test_train_mode_dropout_statistics(H):
