@@ -31,6 +31,20 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _require_fp32_master(p):
+    """Parameters stay fp32 (what AMP / the reference trainer keeps): the kernels read biases and LayerNorm affines as
+    fp32 and cast weights to their bf16 shadows themselves.  model.half() / model.bfloat16() is refused loudly."""
+    if p.dtype != torch.float32:
+        raise TypeError(f"hri_emo_amd: parameter of dtype {p.dtype}; keep the module's parameters in fp32 "
+                        "(the bf16 compute copies are made internally, as under torch.autocast)")
+
+
+def _require_fp32_masters(*ps):
+    for p in ps:
+        if p is not None:
+            _require_fp32_master(p)
+
+
 def _require_gpu(t):
     if not t.is_cuda:
         raise RuntimeError(
@@ -146,9 +160,10 @@ class Shadows:
             s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
                 torch.empty(p.shape, dtype=BF16, device=p.device)
             _require_gpu(p)
+            _require_fp32_master(p)
             src = p.detach()
-            if src.dtype != torch.float32 or not src.is_contiguous():
-                src = src.float().contiguous()
+            if not src.is_contiguous():
+                src = src.contiguous()
             _lib.call("hriemo_cast_f32_to_bf16", _p(src), _p(s), src.numel(), _stream())
             ent = (ver, s)
             self._d[key] = ent
@@ -198,6 +213,7 @@ def padded_shadow(sh, p, kp):
     ver = (p._version, p.data_ptr())
     if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
         _require_gpu(p)
+        _require_fp32_master(p)
         s_ = ent[1] if ent is not None and ent[1].device == p.device else \
             torch.zeros((p.shape[0], kp), dtype=BF16, device=p.device)
         s_[:, :p.shape[1]].copy_(p.detach())
@@ -453,6 +469,7 @@ class SelfAttnLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
         B, L, d = x.shape
@@ -509,6 +526,7 @@ class CrossAttnLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(xq)
         B, Lq, d = xq.shape
@@ -571,6 +589,7 @@ class FFNLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off):
+        _require_fp32_masters(w1, b1, w2, b2, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
         B, L, d = x.shape
@@ -626,6 +645,7 @@ class BetaGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t):
+        _require_fp32_masters(ga, ba, gt, bt, w1, b1, w2, b2)
         _require_gpu(h_a)
         h_a32, h_t32 = _c32(h_a32), _c32(h_t32)
         B, La, d = h_a.shape
@@ -714,6 +734,7 @@ class LegacyBetaGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h_a, h_t, w1, b1, w2, b2, kpm_a, kpm_t):
+        _require_fp32_masters(w1, b1, w2, b2)
         _require_gpu(h_a)
         B, La, d = h_a.shape
         Lt = h_t.shape[1]
@@ -777,6 +798,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, sh):
+        _require_fp32_masters(w, b)
         _require_gpu(x)
         K = x.shape[-1]
         N = w.shape[0]
@@ -830,6 +852,7 @@ class RowDotFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, z32, w, b):
+        _require_fp32_masters(w, b)
         _require_gpu(z)
         B, Ne, d = z.shape
         z2 = _contig_bf16(z).view(B * Ne, d)

@@ -227,6 +227,14 @@ def test_text_longer_than_audio_raises_like_the_reference(H):
             m(cu(h_a), cu(h_t))
 
 
+def test_half_precision_parameters_are_refused_loudly(H):
+    """model.bfloat16() would hand bf16 biases to kernels that read fp32: refused with a TypeError instead."""
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=2, n_heads=8).cuda().bfloat16().eval()
+    h_a, h_t, _, _ = _rand_batch(2, 8, 4, 128, 3, ragged=False)
+    with torch.no_grad(), pytest.raises(TypeError):
+        m(cu(h_a), cu(h_t))
+
+
 def test_train_mode_dropout_statistics(H):
     """dropout=0.1 train-mode forward: finite, differs from eval, and stays near it on average."""
     torch.manual_seed(0)
