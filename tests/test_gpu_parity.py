@@ -235,6 +235,22 @@ def test_half_precision_parameters_are_refused_loudly(H):
         m(cu(h_a), cu(h_t))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_low_precision_inputs_keep_their_dtype(H, dtype):
+    """bf16 / fp16 embeddings (what an autocast region hands over): z comes back in that dtype and everything agrees with the
+    fp32-input result up to the rounding of the inputs."""
+    torch.manual_seed(5)
+    m = fusion(H, 128, 4).eval()
+    h_a, h_t, m_a, m_t = _rand_batch(4, 32, 16, 128, 11)
+    with torch.no_grad():
+        l32, b32, z32 = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+        lx, bx, zx = m(cu(h_a).to(dtype), cu(h_t).to(dtype), cu(m_a), cu(m_t))
+    # z follows the embeddings' dtype; the per-emotion head multiplies z by fp32 parameters, so logits are fp32 (type
+    # promotion does the same in the reference under autocast: emotion_decoder.py:150-158)
+    assert zx.dtype == dtype and lx.dtype == torch.float32
+    close(lx, l32, tol=3e-2, what="logits"); close(zx, z32, tol=3e-2, what="z"); close(bx, b32, tol=3e-2, what="beta")
+
+
 def test_train_mode_dropout_statistics(H):
     """dropout=0.1 train-mode forward: finite, differs from eval, and stays near it on average."""
     torch.manual_seed(0)
