@@ -53,14 +53,20 @@ def _require_gpu(t):
 
 
 _ws_cache = {}
+_ws_retired = []           # outgrown workspaces a captured hipGraph may still point into: never freed
+GRAPHS_ALIVE = 0           # number of captured steps that bake workspace pointers (dp.DataParallelStep.capture)
 
 
 def workspace(nbytes, device, slot=0):
     """Caller-owned scratch for the C ABI (split-K slabs, column-sum partials); grows monotonically.
-    One per (device, slot, stream): the audio and text branches may run on two streams concurrently."""
+    One per (device, slot, stream): the audio and text branches may run on two streams concurrently.
+    Once a step has been captured into a hipGraph the pointers of the workspaces it used are frozen inside the graph:
+    an outgrown buffer is then retired (kept alive), never handed back to the allocator."""
     key = (device.index, slot, torch.cuda.current_stream(device).cuda_stream)
     t = _ws_cache.get(key)
     if t is None or t.numel() * 4 < nbytes:
+        if t is not None and GRAPHS_ALIVE > 0:
+            _ws_retired.append(t)
         n = max(int(nbytes), 64 << 20) // 4 + 16
         t = torch.empty(n, dtype=torch.float32, device=device)
         _ws_cache[key] = t
@@ -121,6 +127,14 @@ def new_site_base():
 
 _seed_words = {}
 CAPTURING = False          # set by dp.DataParallelStep.capture(): weight shadows are re-cast inside the graph
+WEIGHTS_EPOCH = 0          # bumped by anything that rewrites parameter storage behind autograd's back (optim.FusedClipAdamW
+                           # updates the flat buffer through raw pointers: p._version and p.data_ptr() do not move)
+
+
+def bump_weights_epoch():
+    """Invalidate every bf16 weight shadow: the next forward re-casts from the fp32 masters."""
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
 
 
 def seed_word(device):
@@ -155,7 +169,7 @@ class Shadows:
     def get(self, p):
         key = id(p)
         ent = self._d.get(key)
-        ver = (p._version, p.data_ptr())
+        ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
         if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
             s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
                 torch.empty(p.shape, dtype=BF16, device=p.device)
@@ -173,16 +187,27 @@ class Shadows:
 FUSED_WGRAD = True
 
 
+def enable_fused_wgrad(params, on=True):
+    """Opt the given parameters into in-place gradient accumulation (GradSink below).  dp.GradBuckets does this for
+    the parameters whose .grad it owns.  The contract changes for them: the Functions return None for these gradients
+    and write ``p.grad`` directly, bias / LayerNorm gradients are final only when backward() returns (launch-boundary
+    reduce), ``torch.autograd.grad(loss, params)`` yields nothing for them, and tensor / post-accumulate hooks of other
+    libraries (torch DDP, optimizer-in-backward) never see them -- do not combine with foreign gradient hooks."""
+    for p in params:
+        p._hriemo_fused_grad = bool(on)
+
+
 class GradSink:
-    """Where a Function's parameter gradients go.  If every parameter already owns a dense fp32 ``.grad``
-    (zero_grad(set_to_none=False), or the flat-buffer views of dp.GradBuckets) the kernels accumulate
-    straight into it (GEMM / column-reduce ``accumulate`` flag) and the Function returns None for it:
-    no temporary, no autograd add kernel.  Otherwise fresh tensors are returned to autograd as usual."""
+    """Where a Function's parameter gradients go.  Default: fresh tensors returned to autograd (hooks, autograd.grad and
+    foreign reducers work as usual).  If every parameter of the sub-layer was opted in (enable_fused_wgrad; dp.GradBuckets
+    does it for its flat-buffer views) and owns a dense fp32 ``.grad``, the kernels accumulate straight into it (GEMM /
+    column-reduce ``accumulate`` flag) and the Function returns None for it: no temporary, no autograd add kernel."""
 
     def __init__(self, params):
         self.params = params
         self.fused = FUSED_WGRAD and all(
-            p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+            getattr(p, "_hriemo_fused_grad", False)
+            and p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
             and p.grad.device == p.device and p.grad.shape == p.shape for p in params)
         if self.fused:
             for p in params:
@@ -210,7 +235,7 @@ def padded_shadow(sh, p, kp):
     """bf16 shadow of a [N,K] weight zero-padded to [N,kp] (kp = K rounded up to 8: 16-byte rows)"""
     key = (id(p), "pad")
     ent = sh._d.get(key)
-    ver = (p._version, p.data_ptr())
+    ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
     if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
         _require_gpu(p)
         _require_fp32_master(p)

@@ -744,7 +744,10 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int q = min(q0 + r, a.Lq - 1);
-      float p = pad ? 0.f : __expf(dot[r] * a.scale - a.lse[((long)b * a.H + h) * a.Lq + q]);
+      // a query whose keys are ALL PAD has lse = -inf: the reference's softmax over an all -inf row is NaN in every
+      // column (and this kernel family's O is NaN there too), so the exported map says NaN as well, not 0
+      const float lse_q = a.lse[((long)b * a.H + h) * a.Lq + q];
+      float p = (lse_q == -INFINITY) ? __builtin_nanf("") : (pad ? 0.f : __expf(dot[r] * a.scale - lse_q));
       if (a.thr16 != 0) p = keep16(key32, (uint32_t)q, (uint32_t)key, a.thr16) ? p * a.inv_keep : 0.f;
       acc[r] += p;
     }

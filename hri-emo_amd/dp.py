@@ -36,6 +36,7 @@ class GradBuckets:
         for p in order:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            p._hriemo_fused_grad = True          # the kernels may accumulate straight into this view (_ops.GradSink)
             self._offsets[id(p)] = off
             self._bucket_of[id(p)] = len(self.buckets)
             off += pad(n)
@@ -173,12 +174,15 @@ class DataParallelStep:
         graph = torch.cuda.CUDAGraph()
         _ops.CAPTURING = True
         try:
+            # capture on the stream the warm-up ran on: its workspaces (keyed by stream) exist already, so nothing the
+            # graph points into comes from the graph's private pool or is first sized during capture.
             # thread_local: the RCCL watchdog thread may query events while we capture
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 _ops.bump_seed_word(self._static[0].device)
                 self._static_loss = self._fwd_bwd(*self._static)
         finally:
             _ops.CAPTURING = False
+        _ops.GRAPHS_ALIVE += 1            # from now on outgrown workspaces are retired, not freed (_ops.workspace)
         self._graph = graph
         self._replay = True
 

@@ -9,6 +9,7 @@ it moves the parameter storage.  Results follow torch.nn.utils.clip_grad_norm_ +
 import torch
 
 from . import _lib
+from . import _ops
 from ._ops import _p, _stream, _require_gpu
 
 
@@ -43,4 +44,7 @@ class FusedClipAdamW:
         _lib.call("hriemo_rowsum_f32", _p(self._partial), _p(self._norm2), 1, self.nblocks, st)
         _lib.call("hriemo_adamw_flat", _p(self.flat_p), _p(g), _p(self.m), _p(self.v), n, self.lr, self.betas[0], self.betas[1],
                   self.eps, self.wd, self.steps, self.max_norm if self.max_norm else 0.0, _p(self._norm2), st)
+        # the update went through raw pointers: neither p._version nor p.data_ptr() moved, so tell the bf16 weight
+        # shadows explicitly (eager steps would otherwise keep running on the initial weights)
+        _ops.bump_weights_epoch()
         return self._norm2.sqrt()
