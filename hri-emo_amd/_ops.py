@@ -293,6 +293,100 @@ def linear_dw(dy, x, out, accumulate=False):
     gemm(1, 1, N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True, accumulate=accumulate)
 
 
+# ---- MX-fp8 operand path (forward projection / FFN GEMMs; include/hriemo.h "MX-fp8 operand path")
+GEMM_MODE = None           # 'bf16' | 'mx_fp8'; read from HRIEMO_GEMM at first use, set_gemm_mode() changes it at run time
+
+
+def set_gemm_mode(mode):
+    """'bf16' (default) or 'mx_fp8': forward nn.Linear / in-proj / out-proj GEMMs on block-scaled fp8 operands (BASELINE.json
+    configs[4]); attention cores, backward GEMMs, masters and gradients are unchanged."""
+    global GEMM_MODE
+    if mode not in ("bf16", "mx_fp8"):
+        raise ValueError(f"gemm mode {mode!r}: expected 'bf16' or 'mx_fp8'")
+    GEMM_MODE = mode
+
+
+def gemm_mode():
+    global GEMM_MODE
+    if GEMM_MODE is None:
+        import os
+        GEMM_MODE = os.environ.get("HRIEMO_GEMM", "bf16")
+        if GEMM_MODE not in ("bf16", "mx_fp8"):
+            raise ValueError(f"HRIEMO_GEMM={GEMM_MODE!r}: expected 'bf16' or 'mx_fp8'")
+    return GEMM_MODE
+
+
+def mx8_ok(K, N):
+    """shapes the scaled-MFMA kernel takes (a 128-deep step per MFMA); anything else stays on the bf16 GEMM"""
+    return K % 128 == 0 and N % 8 == 0
+
+
+def quant_mx8(x):
+    """x [M,K] bf16 or fp32 (row stride free) -> (e4m3 bytes [M,K], E8M0 scales [K/32, ld])"""
+    M, K = x.shape
+    L_ = _lib.lib()
+    ld = L_.hriemo_mx8_scale_ld(M)
+    q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((K // 32, ld), dtype=torch.uint8, device=x.device)
+    _lib.call("hriemo_quant_mx8", _p(x), x.stride(0), int(x.dtype == torch.float32), M, K, _p(q), K, _p(sc), ld, _stream())
+    return q, sc
+
+
+def linear_fwd_mx8(xq, xs, wq, ws, bias, relu=False, out_f32=False):
+    """(xq, xs) [M,K] and (wq, ws) [N,K] quantised operands -> y [M,N] = x . w^T + bias"""
+    M, K = xq.shape
+    N = wq.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=xq.device)
+    _lib.call("hriemo_gemm_mx8", M, N, K, _p(xq), xq.stride(0), _p(xs), xs.stride(0), _p(wq), wq.stride(0), _p(ws), ws.stride(0),
+              _p(y), N, int(out_f32), _p(bias), 1 if relu else 0, None, 0, _stream())
+    return y
+
+
+def mx8_shadow(sh, p, rows=None):
+    """MX-fp8 copy (bytes, scales) of an fp32 master weight [N,K] (or of its row slice `rows`), refreshed like the bf16 shadow"""
+    key = (id(p), "mx8", rows)
+    ent = sh._d.get(key)
+    ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
+    if CAPTURING or ent is None or ent[0] != ver:
+        _require_gpu(p)
+        _require_fp32_master(p)
+        src = p.detach()
+        if rows is not None:
+            src = src[rows[0]:rows[1]]
+        if not src.is_contiguous():
+            src = src.contiguous()
+        ent = (ver, quant_mx8(src))
+        sh._d[key] = ent
+    return ent[1]
+
+
+class Operand:
+    """A GEMM input in the formats the forward may want: the bf16 rows and, lazily and at most once, their MX-fp8 form."""
+    __slots__ = ("x", "_q")
+
+    def __init__(self, x):
+        self.x, self._q = x, None
+
+    def q(self):
+        if self._q is None:
+            self._q = quant_mx8(self.x)
+        return self._q
+
+
+def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False):
+    """y = x . W[rows]^T + bias[rows] on the configured operand format.  xop: Operand or bf16 tensor"""
+    x = xop.x if isinstance(xop, Operand) else xop
+    K = x.shape[1]
+    N = (rows[1] - rows[0]) if rows is not None else w.shape[0]
+    b = bias if rows is None or bias is None else bias[rows[0]:rows[1]]
+    if gemm_mode() == "mx_fp8" and mx8_ok(K, N):
+        xq, xs = xop.q() if isinstance(xop, Operand) else quant_mx8(x)
+        wq, ws = mx8_shadow(sh, w, rows)
+        return linear_fwd_mx8(xq, xs, wq, ws, b, relu=relu, out_f32=out_f32)
+    wv = w16 if rows is None else w16[rows[0]:rows[1]]
+    return linear_fwd(x, wv, b, relu=relu, out_f32=out_f32)
+
+
 def colsum(x, out, accumulate=False):
     M, N = x.shape
     L_ = _lib.lib()
@@ -504,10 +598,10 @@ class SelfAttnLN(torch.autograd.Function):
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
-        qkv = linear_fwd(x2, w_in16, b_in)
+        qkv = proj_fwd(x2, sh, w_in, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off)
-        g = linear_fwd(o, w_out16, b_out)
+        g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
@@ -562,11 +656,11 @@ class CrossAttnLN(torch.autograd.Function):
         x32v = xq32.view(B * Lq, d) if xq32 is not None else None
         xkv2 = _contig_bf16(xkv).view(B * Lk, d)
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
-        q = linear_fwd(xq2, w_in16[:d], b_in[:d])
-        kv = linear_fwd(xkv2, w_in16[d:], b_in[d:])
+        q = proj_fwd(xq2, sh, w_in, w_in16, b_in, rows=(0, d))
+        kv = proj_fwd(xkv2, sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
         o, lse = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off)
-        g = linear_fwd(o, w_out16, b_out)
+        g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN)
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
@@ -623,13 +717,13 @@ class FFNLN(torch.autograd.Function):
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
         w1_16, w2_16 = sh.get(w1), sh.get(w2)
-        h = linear_fwd(x2, w1_16, b1, relu=True)
+        h = proj_fwd(x2, sh, w1, w1_16, b1, relu=True)
         hd_ = h
         if p_mid > 0:
             hd_ = torch.empty_like(h)
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
-        g = linear_fwd(hd_, w2_16, b2)
+        g = proj_fwd(hd_, sh, w2, w2_16, b2)
         y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
         ctx.save_for_backward(x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
         ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)

@@ -511,8 +511,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
       bf16x4 w;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        w[r] = (bf16_t)(dq[qs][dt][r] * a.scale);
-        cs[dt][r] += (float)w[r];                 // the stored (rounded) values: what a column sum of dQ would read
+        const float v = dq[qs][dt][r] * a.scale;
+        w[r] = (bf16_t)v;
+        cs[dt][r] += v;                           // fp32 values BEFORE the bf16 rounding: the bias gradient does not inherit it
       }
       *(bf16x4*)(dqp + dt * 16) = w;
     }
@@ -686,10 +687,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
       bf16x4 wk, wv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        wk[r] = (bf16_t)(dk[kw][dt][r] * a.scale);
-        wv[r] = (bf16_t)dv[kw][dt][r];
-        csk[dt][r] += (float)wk[r];
-        csv[dt][r] += (float)wv[r];
+        const float vk = dk[kw][dt][r] * a.scale, vv = dv[kw][dt][r];
+        wk[r] = (bf16_t)vk;
+        wv[r] = (bf16_t)vv;
+        csk[dt][r] += vk;
+        csv[dt][r] += vv;
       }
       *(bf16x4*)(dkp + dt * 16) = wk;
       *(bf16x4*)(dvp + dt * 16) = wv;

@@ -33,7 +33,7 @@ void hriemo_set_error(const char* fmt, ...);
   } while (0)
 
 // optional per-kernel-class event timing (bench.py roofline leg); see prof.cpp
-enum { HP_GEMM_NT = 0, HP_GEMM_NN, HP_GEMM_TN, HP_ATTN_FWD, HP_ATTN_BWD_DQ, HP_ATTN_BWD_DKV, HP_ROWOPS, HP_NCLASS };
+enum { HP_GEMM_NT = 0, HP_GEMM_NN, HP_GEMM_TN, HP_ATTN_FWD, HP_ATTN_BWD_DQ, HP_ATTN_BWD_DKV, HP_ROWOPS, HP_GEMM_MX8, HP_NCLASS };
 void hriemo_prof_begin(int cls, hipStream_t s);
 void hriemo_prof_end(int cls, hipStream_t s, double work);
 

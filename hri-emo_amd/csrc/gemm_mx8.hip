@@ -1,0 +1,393 @@
+// MX-fp8 GEMM for gfx950 (BASELINE configs[4]: "fp8 MFMA path"): C[M,N] = A[M,K] . B[N,K]^T with both operands stored as
+// OCP e4m3 bytes + one E8M0 scale per 32 k-elements (OCP microscaling, block size 32), multiplied on
+// v_mfma_scale_f32_16x16x128_f8f6f4 -- the only fp8 form that runs above the bf16 rate on this chip (2x per clock; the
+// plain fp8 16x16x32 runs AT the bf16 rate: scripts_dev/mfma_rate.hip) -- fp32 accumulate, the same fused epilogues
+// (bias, ReLU, ReLU mask, residual add) and the same persistent, LDS-DMA-fed structure as the bf16 kernel (gemm.hip).
+// Sites: every nn.Linear / packed in-projection / out-projection of the fusion blocks and the decoder in the FORWARD
+// direction (models/cross_modal_block_tacfn.py:24-52, models/emotion_decoder.py:14-27); the backward GEMMs stay bf16.
+//
+// Layout notes (measured on hardware by scripts_dev/mx8_probe*.hip, pinned by tests/test_gpu_mx8.py):
+//  * operand lane map of the 128-deep step: lane l = (i = l & 15, g = l >> 4) holds row (column) i and, in registers 0-3,
+//    k = 16g .. 16g+15, in registers 4-7, k = 64+16g .. 64+16g+15 (the instruction is two 64-deep halves side by side);
+//    the scale byte of lane (i, g) -- the byte of its scale VGPR that opsel names -- applies to row i, k = 32g .. 32g+31,
+//    i.e. to bytes held by lanes (i, 2(g&1)) and (i, 2(g&1)+1) in their register half g>>1;
+//  * one K-step = 128 bytes per row = the SAME LDS image as a 64-deep bf16 step ([rows][128 B], 16-B chunk ^= row & 7,
+//    filled by the same buffer_load ... lds stream); a fragment is chunks g and 4+g of its row: the two conflict-free
+//    ds_read_b128 of the bf16 kernel's two half-steps;
+//  * scales travel as [K/32][ld] bytes (k-block major): the four k-blocks of a step x 256 rows are four 256-byte
+//    segments per operand, one buffer_load_dword ... lds each, and a lane fetches its byte with ds_read_u8;
+//  * the matrix pipe needs the same operand BYTES per cycle as the bf16 kernel at twice the FLOPs, so tiles are as
+//    large as there: 256x256 (128x64 per wave, one fragment set, A reloaded in halves) and 256x128 / 128x128
+//    (64x64 per wave, two fragment sets).
+#include "gemm_common.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4v;
+
+// 4-byte-per-lane LDS-DMA (scale segments): 64 lanes x 4 B -> LDS at lds_addr + 4*lane
+__device__ __forceinline__ void lds_dma4(unsigned lds_addr, __attribute__((ext_vector_type(4))) int rsrc, unsigned voff, int soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+
+// 32 operand bytes of lane (i, g) for the row `row` of a [rows][128 B] swizzled image: k = 16g .. 16g+15 (registers 0-3) and
+// k = 64+16g .. 64+16g+15 (registers 4-7), i.e. 16-byte chunks g and 4+g -- the two chunk reads of the bf16 kernel's ks = 0, 1
+__device__ __forceinline__ i32x8 lds_mx_frag(const char* tile, int row, int lane) {
+  const int g = lane >> 4, sw = row & 7;
+  const i32x4v lo = *(LDS_PTR(const i32x4v))(tile + row * 128 + ((g ^ sw) << 4));
+  const i32x4v hi = *(LDS_PTR(const i32x4v))(tile + row * 128 + (((4 + g) ^ sw) << 4));
+  return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int OUTF32, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8_kernel(const GemmArgs p) {
+  constexpr int NWAVE = WM * WN;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SC_BYTES = 8 * 256, STAGE = A_BYTES + B_BYTES + SC_BYTES;
+  constexpr int A_PW = A_BYTES / 1024 / NWAVE, B_PW = B_BYTES / 1024 / NWAVE, S_PW = 8 / NWAVE, LPT = A_PW + B_PW + S_PW;
+  constexpr int MT = BM / WM / 16, NTL = BN / WN / 16;
+  static_assert(A_PW * NWAVE * 1024 == A_BYTES && B_PW * NWAVE * 1024 == B_BYTES && S_PW * NWAVE == 8, "tile must split evenly over waves");
+  static_assert(NS == 2, "two ring slots");
+  static_assert(BM <= 256 && BN <= 256, "a scale segment holds 256 rows");
+  static_assert(MT * NTL <= 16, "64x64 wave tiles: two fragment sets of 72 registers beside 64 accumulators");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  char* scratch = smem + NS * STAGE + wave * 2048;
+
+  const int G = gridDim.x, nxcd = min(8, G), q = G / nxcd, r = G - q * nxcd;
+  const int xcd = blockIdx.x % nxcd, lb = blockIdx.x / nxcd, nx = q + (xcd < r ? 1 : 0);
+  const int before = xcd * q + min(xcd, r);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int end = (int)((long)tiles * (before + nx) / G);
+  const int beg = (int)((long)tiles * before / G);
+  const bool dyn = p.sched != nullptr;
+  unsigned* const qctr = p.sched + xcd;
+  int* const qslot = (int*)(smem + NS * STAGE);
+  auto leave = [&]() {
+    if (dyn && tid == 0) {
+      const unsigned done = atomicAdd(p.sched + 8, 1u);
+      if (done == gridDim.x - 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __hip_atomic_store(p.sched + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  int wg, nwg;
+  if (dyn) {
+    if (tid == 0) {
+      const int first = (int)atomicAdd(qctr, 2u);
+      qslot[0] = beg + first;
+      qslot[1] = beg + first + 1;
+    }
+    __syncthreads();
+    wg = __builtin_amdgcn_readfirstlane(qslot[0]);
+    nwg = __builtin_amdgcn_readfirstlane(qslot[1]);
+    __syncthreads();
+  } else {
+    wg = beg + lb;
+    nwg = wg + nx;
+  }
+  if (wg >= end) { leave(); return; }
+
+  // operands as "bf16 pairs": a 128-byte fp8 row step is byte-for-byte the 64-element bf16 row step of gemm.hip
+  const long lda2 = p.lda / 2, ldb2 = p.ldb / 2;
+  const LaneOff aoff = operand_lane<0, BM, 64>(lda2, lane), boff = operand_lane<0, BN, 64>(ldb2, lane);
+  const int nk = p.K / 128;
+
+  auto decode = [&](int w) {
+    TileInfo t;
+    t.slice = 0;
+    const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
+    t.m0 = tm * BM; t.n0 = tn * BN;
+    t.kext = p.K; t.nk = nk;
+    t.abase = (const bf16_t*)((const uint8_t*)p.A + (long)t.m0 * p.lda);
+    t.bbase = (const bf16_t*)((const uint8_t*)p.B + (long)t.n0 * p.ldb);
+    t.a_valid = p.M - t.m0; t.b_valid = p.N - t.n0;
+    return t;
+  };
+  constexpr bool REBUILD = false;
+  auto stage = [&](int s, const TileInfo& t, int kstep) {
+    char* sa = smem + s * STAGE;
+    if (REBUILD) {
+      int l2 = lane;
+      asm volatile("" : "+v"(l2));
+      const LaneOff ao = operand_lane<0, BM, 64>(lda2, l2), bo = operand_lane<0, BN, 64>(ldb2, l2);
+      stage_operand<0, BM, A_PW, 64>(sa, t.abase + kstep * 64, ao, lda2, t.a_valid, 64, wave, lane);
+      stage_operand<0, BN, B_PW, 64>(sa + A_BYTES, t.bbase + kstep * 64, bo, ldb2, t.b_valid, 64, wave, lane);
+    } else {
+      stage_operand<0, BM, A_PW, 64>(sa, t.abase + kstep * 64, aoff, lda2, t.a_valid, 64, wave, lane);
+      stage_operand<0, BN, B_PW, 64>(sa + A_BYTES, t.bbase + kstep * 64, boff, ldb2, t.b_valid, 64, wave, lane);
+    }
+    // scale segments: 0..3 = A k-blocks 4*kstep .. +3 (rows m0 .. m0+BM-1), 4..7 = B.  Rows beyond the matrix edge read
+    // the padding of the scale row (ld is a multiple of 256 by contract): they only reach accumulators that are never stored.
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+#pragma unroll
+    for (int t2 = 0; t2 < S_PW; ++t2) {
+      const int seg = wave * S_PW + t2;                     // wave-uniform
+      const bool isb = seg >= 4;
+      const uint8_t* src = isb ? p.SB + (long)(kstep * 4 + seg - 4) * p.ldsb + t.n0 : p.SA + (long)(kstep * 4 + seg) * p.ldsa + t.m0;
+      const unsigned long sb_ = (unsigned long)src;
+      const i32x4 rs = {(int)(unsigned)sb_, (int)((sb_ >> 32) & 0xffffu), (int)OOB_OFF, 0x00020000};
+      const int rows = isb ? BN : BM;
+      const unsigned vo = (lane * 4 < rows) ? (unsigned)(lane * 4) : OOB_OFF;
+      lds_dma4((unsigned)(unsigned long)(LDS_PTR(char))(sa + A_BYTES + B_BYTES + seg * 256), rs, vo, 0);
+    }
+  };
+
+  f32x4 acc[MT][NTL];
+  struct Frags { i32x8 a[MT]; i32x8 b[NTL]; int sa[MT]; int sb[NTL]; };
+  auto load_frags = [&](const char* st, Frags& f) {
+    const int g = lane >> 4, i = lane & 15;
+    const char* sc = st + A_BYTES + B_BYTES;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int row = wm * MT * 16 + mi * 16 + i;
+      f.a[mi] = lds_mx_frag(st, row, lane);
+      f.sa[mi] = (int)*(LDS_PTR(const uint8_t))(sc + g * 256 + row);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NTL; ++ni) {
+      const int row = wn * NTL * 16 + ni * 16 + i;
+      f.b[ni] = lds_mx_frag(st + A_BYTES, row, lane);
+      f.sb[ni] = (int)*(LDS_PTR(const uint8_t))(sc + (4 + g) * 256 + row);
+    }
+  };
+  auto mma_rows = [&](const Frags& f, int lo, int hi) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+      if (mi >= lo && mi < hi) {
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni)     // transposed product: the weight fragment is the A operand, so a lane owns 4 columns of a row
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0, f.sb[ni], 0, f.sa[mi]);
+      }
+  };
+
+  // The operand stream is one sequence of 128-deep steps over (tile, K-step), every tile padded to an EVEN number of
+  // steps (a padding step is staged with every lane out of range: zero operands, zero scale bytes, adds nothing), so the
+  // two fragment sets keep fixed roles: even steps compute on set A and read set B, odd steps the other way round, and a
+  // tile always ends with the NEXT tile's first fragments in set A.  Every step is the same unconditional code:
+  //   DMA(position s+1) | MFMA(rows 0..MT/2 of s) | retire s+1, barrier | read fragments of s+1 | MFMA(rows MT/2..MT of s)
+  // All reads of a stage happen between the barrier that publishes it and the next one, i.e. before its slot is restaged.
+  const int nkp = (nk + 1) & ~1;
+  TileInfo T = decode(wg);
+  auto stage_pos = [&](int slot, const TileInfo& t, int ks) {
+    if (ks < nk) { stage(slot, t, ks); return; }
+    // padding step: same number of DMA instructions (vmcnt bookkeeping), every lane out of range -> zeros
+    char* sa = smem + slot * STAGE;
+    const LaneOff oob = {OOB_OFF, 0};
+    stage_operand<0, BM, A_PW, 64>(sa, t.abase, oob, lda2, 0, 0, wave, lane);
+    stage_operand<0, BN, B_PW, 64>(sa + A_BYTES, t.bbase, oob, ldb2, 0, 0, wave, lane);
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const unsigned long sb_ = (unsigned long)p.SA;
+    const i32x4 rs = {(int)(unsigned)sb_, (int)((sb_ >> 32) & 0xffffu), (int)OOB_OFF, 0x00020000};
+#pragma unroll
+    for (int t2 = 0; t2 < S_PW; ++t2)
+      lds_dma4((unsigned)(unsigned long)(LDS_PTR(char))(sa + A_BYTES + B_BYTES + (wave * S_PW + t2) * 256), rs, OOB_OFF, 0);
+  };
+  stage_pos(0, T, 0);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt = 1;
+  bool parked = false;
+  Frags fA, fB;
+  load_frags(smem, fA);
+  for (;;) {
+    if (parked) {
+      __builtin_amdgcn_s_barrier();     // the id parked by wave 0 after its last epilogue is visible
+      nwg = __builtin_amdgcn_readfirstlane(qslot[0]);
+    }
+    const bool has_next = nwg < end;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto kstep = [&](int s, Frags& fc, Frags& fn) {
+      if (s + 1 < nkp) stage_pos(nxt, T, s + 1);
+      else if (has_next) { const TileInfo NX = decode(nwg); stage_pos(nxt, NX, 0); }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      mma_rows(fc, 0, MT / 2);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      cur ^= 1; nxt ^= 1;
+      wait_vmcnt<0>();                              // this wave's share of position s+1 has landed ...
+      __builtin_amdgcn_s_waitcnt(0xC07F);           // ... its reads of position s are complete (slot may be restaged) ...
+      __builtin_amdgcn_s_barrier();                 // ... and everybody's
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(smem + cur * STAGE, fn);           // lands under the second cluster (garbage, never used, after the last position)
+      __builtin_amdgcn_s_setprio(1);
+      mma_rows(fc, MT / 2, MT);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s = 0; s < nkp; s += 2) { kstep(s, fA, fB); kstep(s + 1, fB, fA); }
+    int drawn = end;
+    if (dyn && has_next && tid == 0) drawn = beg + (int)atomicAdd(qctr, 1u);
+    if (OUTF32) {
+      store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
+    } else {
+      switch (p.epi) {
+        case 1: store_tile<0, 1, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        case 2: store_tile<0, 2, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        case 3: store_tile<0, 3, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        default: store_tile<0, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+      }
+    }
+    if (!has_next) break;
+    T = decode(nwg);
+    wg = nwg;
+    if (dyn) {
+      if (tid == 0) qslot[0] = drawn;
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      parked = true;
+    } else {
+      nwg = wg + nx;
+    }
+  }
+  leave();
+}
+
+// ------------------------------------------------------------------------------------------------ quantiser
+// X[M][K] (bf16 or fp32) -> Xq[M][K] e4m3 bytes + S[K/32][lds] E8M0 bytes.  Per 32-element block: scale 2^e with
+// e = ceil(log2(amax / 448)) (the smallest power of two that brings the block inside e4m3's finite range, so nothing
+// saturates), elements = round-to-nearest-even(x * 2^-e).  amax == 0 -> e = -127 (byte 0), elements 0.
+// One wave per row (8 elements per lane and pass), 64 rows per block; the block's scale bytes are staged in LDS and leave
+// as 64-byte segments of the k-block-major scale rows.
+template <typename TIN>
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const TIN* __restrict__ X, long ldx, int M, int K, uint8_t* __restrict__ Q, long ldq,
+                                                        uint8_t* __restrict__ S, long lds_) {
+  extern __shared__ __attribute__((aligned(16))) char smem_q[];     // [K/32][64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * 64;
+  const int nkb = K >> 5;
+  for (int rr = wave; rr < 64; rr += 4) {
+    const int row = row0 + rr;
+    if (row >= M) {                                 // rows past the edge: neutral scale bytes (never used by a stored output)
+      for (int kb = lane; kb < nkb; kb += 64) smem_q[kb * 64 + rr] = 127;
+      continue;
+    }
+    for (int c0 = 0; c0 < K; c0 += 512) {
+      const int c = c0 + lane * 8;
+      float f[8];
+      if (c < K) {
+        if constexpr (sizeof(TIN) == 2) {
+          bf8_to_f32(*(const bf16x8*)((const bf16_t*)X + (long)row * ldx + c), f);
+        } else {
+          const f32x4 a = *(const f32x4*)((const float*)X + (long)row * ldx + c), b = *(const f32x4*)((const float*)X + (long)row * ldx + c + 4);
+          f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      }
+      float amax = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+      amax = fmaxf(amax, __shfl_xor(amax, 1));
+      amax = fmaxf(amax, __shfl_xor(amax, 2));        // 4 lanes x 8 elements = one 32-block
+      // e = ceil(log2(amax / 448)) exactly, from the bits: amax = 1.m x 2^Ea fits under 448 x 2^e = 1.75 x 2^(e+8)
+      // iff e >= Ea - 8 (1.m <= 1.75) or e >= Ea - 7 (1.m > 1.75)
+      const unsigned ab = __float_as_uint(amax);
+      int e = (int)(ab >> 23) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);     // biased (E8M0) exponent of the scale
+      e = amax == 0.f ? 0 : (e < 1 ? 1 : (e > 253 ? 253 : e));
+      const float inv = amax == 0.f ? 0.f : __uint_as_float((unsigned)(254 - e) << 23);     // 2^-(e-127)
+      if (c < K) {
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, w1, true);
+        typedef __attribute__((ext_vector_type(2))) int i32x2;
+        *(i32x2*)(Q + (long)row * ldq + c) = (i32x2){w0, w1};
+        if ((lane & 3) == 0) smem_q[(c >> 5) * 64 + rr] = (char)e;
+      }
+    }
+  }
+  __syncthreads();
+  // scale bytes out: [nkb][64] -> S[kb][row0 .. row0+63], 4 bytes per thread-iteration (the scale rows are padded to 256)
+  for (int idx = threadIdx.x; idx < nkb * 16; idx += 256) {
+    const int kb = idx >> 4, part = idx & 15;
+    *(unsigned*)(S + (long)kb * lds_ + row0 + part * 4) = *(const unsigned*)(smem_q + kb * 64 + part * 4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct MxCfg { int bm, bn, wm, wn; };
+static const MxCfg kMx[] = {
+    {256, 128, 4, 2},     // 0: 64x64 per wave, 8 waves, one block per CU
+    {128, 128, 2, 2},     // 1: 64x64 per wave, 4 waves, two blocks per CU
+};
+static int g_force_mx = -1;
+extern "C" int hriemo_gemm_mx8_force_config(int cfg) {
+  g_force_mx = (cfg >= 0 && cfg < 2) ? cfg : -1;
+  return 0;
+}
+
+template <int OUTF32, int BM, int BN, int WM, int WN>
+static void launch_mx(const GemmArgs& a, hipStream_t st) {
+  constexpr int NS = 2;
+  const int lds = NS * (BM * 128 + BN * 128 + 2048) + WM * WN * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_mx8_kernel<OUTF32, BM, BN, WM, WN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const long units = (long)a.tiles_m * a.tiles_n;
+  const long slots = (long)hriemo_num_cus() * (lds <= 80 * 1024 ? 2 : 1);
+  const int grid = (int)(units < slots ? units : slots);
+  GemmArgs q = a;
+  q.sched = units > slots ? hriemo_gemm_sched_slot(st) : nullptr;
+  hipLaunchKernelGGL((gemm_mx8_kernel<OUTF32, BM, BN, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, q);
+}
+
+extern "C" int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
+                               const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
+                               const void* aux, long ldaux, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && N > 0 && K > 0, "gemm_mx8: empty problem M=%d N=%d K=%d", M, N, K);
+  HRIEMO_CHECK(K % 128 == 0, "gemm_mx8: K=%d must be a multiple of 128 (one scaled MFMA step)", K);
+  HRIEMO_CHECK(N % 8 == 0, "gemm_mx8: N=%d must be a multiple of 8", N);
+  HRIEMO_CHECK(lda % 16 == 0 && ldb % 16 == 0 && ldc % (c_is_f32 ? 4 : 8) == 0, "gemm_mx8: leading dims must keep 16-byte alignment");
+  HRIEMO_CHECK(ldsa % 256 == 0 && ldsb % 256 == 0 && ldsa >= M && ldsb >= N, "gemm_mx8: scale rows must be padded to a multiple of 256 (ldsa=%ld ldsb=%ld)", ldsa, ldsb);
+  HRIEMO_CHECK(((uintptr_t)Aq % 16) == 0 && ((uintptr_t)Bq % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)SA % 4) == 0 && ((uintptr_t)SB % 4) == 0, "gemm_mx8: unaligned operand");
+  HRIEMO_CHECK(lda < (1L << 22) && ldb < (1L << 22), "gemm_mx8: leading dimension too large for 32-bit tile offsets");
+  HRIEMO_CHECK(c_is_f32 || (epilogue >= 0 && epilogue <= 3), "gemm_mx8: bad epilogue");
+  HRIEMO_CHECK(epilogue < 2 || (aux != nullptr && ldaux % 8 == 0 && ((uintptr_t)aux % 16) == 0), "gemm_mx8: epilogue 2/3 needs a 16-byte aligned aux");
+  HRIEMO_CHECK(!(c_is_f32 && epilogue != 0), "gemm_mx8: fp32 output has no activation epilogue");
+  int cfg = g_force_mx;
+  if (cfg < 0) cfg = (M < 1024 || N < 256) ? 1 : 0;
+  GemmArgs a = {};
+  a.M = M; a.N = N; a.K = K;
+  a.A = (const bf16_t*)Aq; a.lda = lda; a.B = (const bf16_t*)Bq; a.ldb = ldb;
+  a.SA = (const uint8_t*)SA; a.ldsa = ldsa; a.SB = (const uint8_t*)SB; a.ldsb = ldsb;
+  a.C = C; a.ldc = ldc; a.bias = bias; a.aux = (const bf16_t*)aux; a.ldaux = ldaux; a.epi = epilogue;
+  a.tiles_m = (M + kMx[cfg].bm - 1) / kMx[cfg].bm; a.tiles_n = (N + kMx[cfg].bn - 1) / kMx[cfg].bn;
+  a.splitk = 1; a.k_per_split = K; a.ws = nullptr; a.accumulate = 0; a.sched = nullptr;
+  hriemo_prof_begin(HP_GEMM_MX8, st);
+  if (c_is_f32) {
+    if (cfg == 0) launch_mx<1, 256, 128, 4, 2>(a, st); else launch_mx<1, 128, 128, 2, 2>(a, st);
+  } else {
+    if (cfg == 0) launch_mx<0, 256, 128, 4, 2>(a, st); else launch_mx<0, 128, 128, 2, 2>(a, st);
+  }
+  HRIEMO_LAUNCH_CHECK("gemm_mx8_kernel");
+  hriemo_prof_end(HP_GEMM_MX8, st, 2.0 * M * N * K);
+  return 0;
+}
+
+extern "C" long hriemo_mx8_scale_ld(int rows) { return ((long)rows + 255) / 256 * 256; }
+
+extern "C" int hriemo_quant_mx8(const void* X, long ldx, int src_is_f32, int M, int K, void* Xq, long ldq, void* S, long lds_,
+                                hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && K > 0 && K % 32 == 0 && K <= 32768, "quant_mx8: K=%d must be a positive multiple of 32 (<= 32768)", K);
+  HRIEMO_CHECK(ldx % 8 == 0 && ldq % 8 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Xq % 8) == 0, "quant_mx8: unaligned operand");
+  HRIEMO_CHECK(lds_ % 256 == 0 && lds_ >= M && ((uintptr_t)S % 4) == 0, "quant_mx8: scale rows must be padded to a multiple of 256");
+  const int grid = (M + 63) / 64, smem = (K / 32) * 64;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  if (src_is_f32) hipLaunchKernelGGL((quant_mx8_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)X, ldx, M, K, (uint8_t*)Xq, ldq, (uint8_t*)S, lds_);
+  else hipLaunchKernelGGL((quant_mx8_kernel<bf16_t>), dim3(grid), dim3(256), smem, st, (const bf16_t*)X, ldx, M, K, (uint8_t*)Xq, ldq, (uint8_t*)S, lds_);
+  HRIEMO_LAUNCH_CHECK("quant_mx8_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (double)M * K * (src_is_f32 ? 5 : 3) + (double)M * K / 32);
+  return 0;
+}

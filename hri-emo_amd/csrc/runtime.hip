@@ -62,7 +62,7 @@ extern "C" int hriemo_prof_nclass(void) { return HP_NCLASS; }
 
 extern "C" const char* hriemo_prof_name(int cls) {
   static const char* names[HP_NCLASS] = {"gemm_bf16_nt", "gemm_bf16_nn", "gemm_bf16_tn", "attn_fwd",
-                                         "attn_bwd_dq",  "attn_bwd_dkv", "rowops"};
+                                         "attn_bwd_dq",  "attn_bwd_dkv", "rowops", "gemm_mx8_nt"};
   return (cls >= 0 && cls < HP_NCLASS) ? names[cls] : "?";
 }
 

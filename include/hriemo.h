@@ -47,6 +47,23 @@ int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long ld
 /* tuning hook: force one of the built tile configurations (-1 = built-in heuristic) */
 int hriemo_gemm_force_config(int cfg);
 
+/* ---- MX-fp8 operand path (BASELINE.json configs[4], "fp8 MFMA path"): the same nn.Linear / in-projection / out-projection
+ * sites as hriemo_gemm_bf16 in the FORWARD direction (models/cross_modal_block_tacfn.py:24-52, models/emotion_decoder.py:14-27),
+ * with both operands as OCP e4m3 bytes + one E8M0 scale byte per 32 k-elements (OCP microscaling, block 32), multiplied on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with fp32 accumulation.  Attention cores, backward GEMMs, masters and gradients keep
+ * their bf16 / fp32 formats.
+ *   hriemo_quant_mx8: X[M,K] (bf16, or fp32 when src_is_f32: weight masters) -> Xq[M,K] bytes (row stride ldq) and scales
+ *     S[K/32][lds] (k-block major; lds = hriemo_mx8_scale_ld(M), a multiple of 256 >= M).  Block scale = 2^ceil(log2(amax/448)):
+ *     nothing saturates; elements round to nearest even.
+ *   hriemo_gemm_mx8: C[M,N] = A[M,K] . B[N,K]^T (+bias) with the epilogues of hriemo_gemm_bf16; K % 128 == 0. */
+long hriemo_mx8_scale_ld(int rows);
+int hriemo_quant_mx8(const void* X, long ldx, int src_is_f32, int M, int K, void* Xq, long ldq, void* S, long lds,
+                     hriemo_stream_t stream);
+int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
+                    const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
+                    const void* aux, long ldaux, hriemo_stream_t stream);
+int hriemo_gemm_mx8_force_config(int cfg);
+
 /* ---- attention core: softmax(QK^T/sqrt(hd) + mask) -> dropout -> .V per (batch, head), flash style.
  * Q/K/V/O/dX are read/written in place inside the projection buffers: element (b, l, h, e) of X is
  * X[(b*L + l)*ldx + h*head_dim + e].  lse [B,H,Lq] (natural log) is written by fwd, read by bwd/probs;

@@ -1,0 +1,272 @@
+"""GPU suite, kernel level, part 2: the beta-gate / pooling / fusion / dropout row kernels, each called THROUGH THE C ABI
+(include/hriemo.h, ctypes) and compared with plain torch fp32 math on the same inputs.
+
+Reference arithmetic: models/beta_gate_tacfn.py:6-24 (masked_mean), :79-84 (LayerNorm + pools), :87-95 (gate input, sigmoid,
+beta), :98-116 (fusion over the first L positions); models/beta_gate.py:6-32,97-112 (legacy scalar gate);
+models/emotion_decoder.py:58 (mid-FFN dropout).  Tolerances are stated per check: fp32 results 1e-5-ish, bf16 outputs one
+bf16 ulp of the value range (2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import hashrng
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import hri_emo_amd  # noqa: F401
+    from hri_emo_amd import _lib
+    return _lib
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def ST():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32(*shape):
+    return torch.empty(shape, dtype=torch.float32, device="cuda")
+
+
+def bf(*shape):
+    return torch.empty(shape, dtype=torch.bfloat16, device="cuda")
+
+
+def relerr(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def ragged_mask(B, L, g, lo_frac=0.4):
+    lens = torch.randint(max(1, int(L * lo_frac)), L + 1, (B,), generator=g)
+    return torch.arange(L)[None, :] >= lens[:, None]
+
+
+GATE_CASES = [  # B, La, Lt, d, masked, twin
+    (3, 40, 17, 128, True, False),
+    (2, 400, 128, 768, True, True),
+    (4, 33, 33, 256, False, True),        # equal lengths, no masks (mask pointers NULL)
+    (2, 70, 5, 1024, True, True),
+    (1, 1, 1, 128, False, False),
+]
+
+
+@pytest.mark.parametrize("B,La,Lt,d,masked,twin", GATE_CASES)
+def test_gate_forward_chain_through_c_abi(lib, B, La, Lt, d, masked, twin):
+    """hriemo_ln_pool_fwd (x2) -> hriemo_gate_input -> hriemo_sigmoid_beta -> hriemo_fuse_fwd against
+    LayerNorm / masked mean / cat[a,t,|a-t|,a*t] / sigmoid / w*A+(1-w)*T in fp32 (beta_gate_tacfn.py:79-116)."""
+    g = torch.Generator().manual_seed(1000 + La + d)
+    L = Lt
+    xa32, xt32 = torch.randn(B, La, d, generator=g) * 1.3 + 0.2, torch.randn(B, Lt, d, generator=g)
+    xa, xt = xa32.bfloat16(), xt32.bfloat16()
+    ga, ba = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    gt, bt = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    ma = ragged_mask(B, La, g) if masked else None
+    mt = ragged_mask(B, Lt, g) if masked else None
+    src_a = xa32 if twin else xa.float()            # the fp32 twin wins over the bf16 copy when given
+    src_t = xt32 if twin else xt.float()
+    An_r, Tn_r = F.layer_norm(src_a, (d,), ga, ba, 1e-5), F.layer_norm(src_t, (d,), gt, bt, 1e-5)
+
+    def mmean(x, m):
+        if m is None:
+            return x.mean(1), torch.full((x.shape[0],), float(x.shape[1]))
+        v = (~m).float()
+        return (x * v[..., None]).sum(1) / v.sum(1).clamp(min=1)[:, None], v.sum(1).clamp(min=1)
+
+    ap_r, ca_r = mmean(An_r, ma)
+    tp_r, ct_r = mmean(Tn_r, mt)
+
+    nca, nct = lib.lib().hriemo_pool_chunks(La), lib.lib().hriemo_pool_chunks(Lt)
+    An, Tn = bf(B, L, d), bf(B, L, d)
+    mean_a, rstd_a, mean_t, rstd_t = f32(B * La), f32(B * La), f32(B * Lt), f32(B * Lt)
+    pa, pt = f32(B, nca, d), f32(B, nct, d)
+    xa_d, xt_d = xa.cuda(), xt.cuda()
+    xa32_d, xt32_d = (xa32.cuda(), xt32.cuda()) if twin else (None, None)
+    ma_d = ma.cuda().view(torch.uint8) if ma is not None else None
+    mt_d = mt.cuda().view(torch.uint8) if mt is not None else None
+    ga_d, ba_d, gt_d, bt_d = ga.cuda(), ba.cuda(), gt.cuda(), bt.cuda()
+    lib.call("hriemo_ln_pool_fwd", P(xa_d), P(xa32_d), P(ma_d), P(ga_d), P(ba_d), P(An), P(mean_a), P(rstd_a), P(pa), B, La, L, d,
+             1e-5, ST())
+    lib.call("hriemo_ln_pool_fwd", P(xt_d), P(xt32_d), P(mt_d), P(gt_d), P(bt_d), P(Tn), P(mean_t), P(rstd_t), P(pt), B, Lt, L, d,
+             1e-5, ST())
+    assert relerr(An, An_r[:, :L]) <= 2 ** -8 and relerr(Tn, Tn_r[:, :L]) <= 2 ** -8             # bf16 outputs
+    assert (mean_a.cpu() - src_a.mean(-1).reshape(-1)).abs().max() <= 1e-5
+    var = src_a.var(-1, unbiased=False).reshape(-1)
+    assert relerr(rstd_a, (var + 1e-5).rsqrt()) <= 1e-5
+
+    gin, a_pool, t_pool, cnt = bf(B, 4 * d), f32(B, d), f32(B, d), f32(B, 2)
+    lib.call("hriemo_gate_input", P(pa), P(pt), P(ma_d), P(mt_d), B, La, Lt, d, P(gin), P(a_pool), P(t_pool), P(cnt), ST())
+    assert (a_pool.cpu() - ap_r).abs().max() <= 2e-5 * max(1.0, ap_r.abs().max().item())      # fp32 pools of fp32 LN values
+    assert (t_pool.cpu() - tp_r).abs().max() <= 2e-5 * max(1.0, tp_r.abs().max().item())
+    assert torch.equal(cnt.cpu(), torch.stack([ca_r, ct_r], 1))
+    gin_r = torch.cat([ap_r, tp_r, (ap_r - tp_r).abs(), ap_r * tp_r], -1)
+    assert (gin.float().cpu() - gin_r).abs().max() <= 2 ** -8 * max(1.0, gin_r.abs().max().item())
+
+    pre = (torch.randn(B, d, generator=g) * 2).cuda()
+    w, beta = f32(B, d), f32(B, 1)
+    lib.call("hriemo_sigmoid_beta", P(pre), P(w), P(beta), B, d, ST())
+    assert (w.cpu() - torch.sigmoid(pre.cpu())).abs().max() <= 2e-6
+    assert (beta.cpu() - torch.sigmoid(pre.cpu()).mean(-1, keepdim=True)).abs().max() <= 2e-6
+
+    H = bf(B, L, d)
+    lib.call("hriemo_fuse_fwd", P(w), P(An), P(Tn), P(H), B, L, d, ST())
+    H_r = w.cpu()[:, None, :] * An.float().cpu() + (1 - w.cpu()[:, None, :]) * Tn.float().cpu()   # from the kernel's own bf16 A, T
+    assert (H.float().cpu() - H_r).abs().max() <= 2 ** -8 * max(1.0, H_r.abs().max().item())
+
+
+@pytest.mark.parametrize("B,La,Lt,d,masked,twin", GATE_CASES)
+def test_gate_backward_chain_through_c_abi(lib, B, La, Lt, d, masked, twin):
+    """hriemo_fuse_bwd_dw -> hriemo_gate_dpre -> hriemo_gate_input_bwd -> hriemo_ln_pool_bwd (both modalities) against
+    torch autograd of the same fp32 graph, fed with the same upstream gradients (dH, dbeta, d gate_in)."""
+    g = torch.Generator().manual_seed(2000 + La + d)
+    L = Lt
+    xa32, xt32 = torch.randn(B, La, d, generator=g) * 1.3 + 0.2, torch.randn(B, Lt, d, generator=g)
+    xa, xt = xa32.bfloat16(), xt32.bfloat16()
+    ga, gt = 1 + 0.1 * torch.randn(d, generator=g), 1 + 0.1 * torch.randn(d, generator=g)
+    ba, bt = torch.zeros(d), torch.zeros(d)
+    ma = ragged_mask(B, La, g) if masked else None
+    mt = ragged_mask(B, Lt, g) if masked else None
+    dH = torch.randn(B, L, d, generator=g).bfloat16()
+    dbeta = torch.randn(B, 1, generator=g)
+    dgin = (torch.randn(B, 4 * d, generator=g) * 0.5).bfloat16()
+    wv = torch.sigmoid(torch.randn(B, d, generator=g))
+
+    # ---- torch reference graph: (x_a, x_t, gamma/beta, w, gate_in) -> scalar
+    src_a = (xa32 if twin else xa.float()).clone().requires_grad_(True)
+    src_t = (xt32 if twin else xt.float()).clone().requires_grad_(True)
+    ga_r, ba_r = ga.clone().requires_grad_(True), ba.clone().requires_grad_(True)
+    gt_r, bt_r = gt.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    w_r = wv.clone().requires_grad_(True)
+    An_r, Tn_r = F.layer_norm(src_a, (d,), ga_r, ba_r, 1e-5), F.layer_norm(src_t, (d,), gt_r, bt_r, 1e-5)
+
+    def mmean(x, m):
+        if m is None:
+            return x.mean(1)
+        v = (~m).float()
+        return (x * v[..., None]).sum(1) / v.sum(1).clamp(min=1)[:, None]
+
+    ap_r, tp_r = mmean(An_r, ma), mmean(Tn_r, mt)
+    gin_r = torch.cat([ap_r, tp_r, (ap_r - tp_r).abs(), ap_r * tp_r], -1)
+    H_r = w_r[:, None, :] * An_r[:, :L] + (1 - w_r[:, None, :]) * Tn_r[:, :L]
+    obj = (H_r * dH.float()).sum() + (w_r.mean(-1, keepdim=True) * dbeta).sum() + (gin_r * dgin.float()).sum()
+    obj.backward()
+
+    # ---- the kernels, forward first (saved tensors), then every backward entry point
+    nca, nct, ncl = (lib.lib().hriemo_pool_chunks(x) for x in (La, Lt, L))
+    An, Tn = bf(B, L, d), bf(B, L, d)
+    mean_a, rstd_a, mean_t, rstd_t = f32(B * La), f32(B * La), f32(B * Lt), f32(B * Lt)
+    pa, pt = f32(B, nca, d), f32(B, nct, d)
+    xa_d, xt_d = xa.cuda(), xt.cuda()
+    xa32_d, xt32_d = (xa32.cuda(), xt32.cuda()) if twin else (None, None)
+    ma_d = ma.cuda().view(torch.uint8) if ma is not None else None
+    mt_d = mt.cuda().view(torch.uint8) if mt is not None else None
+    ga_d, ba_d, gt_d, bt_d = ga.cuda(), ba.cuda(), gt.cuda(), bt.cuda()
+    lib.call("hriemo_ln_pool_fwd", P(xa_d), P(xa32_d), P(ma_d), P(ga_d), P(ba_d), P(An), P(mean_a), P(rstd_a), P(pa), B, La, L, d,
+             1e-5, ST())
+    lib.call("hriemo_ln_pool_fwd", P(xt_d), P(xt32_d), P(mt_d), P(gt_d), P(bt_d), P(Tn), P(mean_t), P(rstd_t), P(pt), B, Lt, L, d,
+             1e-5, ST())
+    gin, a_pool, t_pool, cnt = bf(B, 4 * d), f32(B, d), f32(B, d), f32(B, 2)
+    lib.call("hriemo_gate_input", P(pa), P(pt), P(ma_d), P(mt_d), B, La, Lt, d, P(gin), P(a_pool), P(t_pool), P(cnt), ST())
+
+    dH_d, w_d, dbeta_d, dgin_d = dH.cuda(), wv.cuda(), dbeta.cuda().contiguous(), dgin.cuda()
+    part = f32(B, ncl, d)
+    lib.call("hriemo_fuse_bwd_dw", P(dH_d), P(An), P(Tn), P(part), B, L, d, ST())
+    dw_ref = (dH.float() * (An.float().cpu() - Tn.float().cpu())).sum(1)                 # from the kernel's own bf16 A, T
+    assert (part.sum(1).cpu() - dw_ref).abs().max() <= 1e-4 * max(1.0, dw_ref.abs().max().item())
+    dpre = bf(B, d)
+    lib.call("hriemo_gate_dpre", P(part), L, P(dbeta_d), P(w_d), P(dpre), B, d, ST())
+    dpre_ref = (dw_ref + dbeta / d) * wv * (1 - wv)
+    assert (dpre.float().cpu() - dpre_ref).abs().max() <= 2 ** -8 * max(1e-3, dpre_ref.abs().max().item())
+    # against autograd: dw of the fp32 graph (A, T unrounded) -- bf16 A/T cost ~2^-8 relative per term
+    assert relerr(part.sum(1) + dbeta_d / d, w_r.grad) <= 2e-2
+
+    da, dt = f32(B, d), f32(B, d)
+    lib.call("hriemo_gate_input_bwd", P(dgin_d), P(a_pool), P(t_pool), P(cnt), P(da), P(dt), B, d, ST())
+    a_, t_, gi = a_pool.cpu(), t_pool.cpu(), dgin.float()
+    sg = torch.sign(a_ - t_)
+    da_ref = (gi[:, :d] + sg * gi[:, 2 * d:3 * d] + t_ * gi[:, 3 * d:]) / cnt.cpu()[:, :1]
+    dt_ref = (gi[:, d:2 * d] - sg * gi[:, 2 * d:3 * d] + a_ * gi[:, 3 * d:]) / cnt.cpu()[:, 1:]
+    assert (da.cpu() - da_ref).abs().max() <= 1e-5 * max(1.0, da_ref.abs().max().item())
+    assert (dt.cpu() - dt_ref).abs().max() <= 1e-5 * max(1.0, dt_ref.abs().max().item())
+
+    dxa, dxt = bf(B, La, d), bf(B, Lt, d)
+    dga, dba, dgt, dbt = f32(d), f32(d), f32(d), f32(d)
+    wsb = max(lib.lib().hriemo_ln_pool_bwd_workspace_bytes(B, La, d), lib.lib().hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d))
+    ws = f32(wsb // 4 + 16)
+    lib.call("hriemo_ln_pool_bwd", P(dH_d), L, P(w_d), 1, P(da), P(ma_d), P(xa_d), P(xa32_d), P(ga_d), P(mean_a), P(rstd_a), P(dxa),
+             P(dga), P(dba), B, La, d, P(ws), ST())
+    lib.call("hriemo_ln_pool_bwd", P(dH_d), L, P(w_d), 0, P(dt), P(mt_d), P(xt_d), P(xt32_d), P(gt_d), P(mean_t), P(rstd_t), P(dxt),
+             P(dgt), P(dbt), B, Lt, d, P(ws), ST())
+    # dX: bf16 output of O(1) values; everything upstream of it is fp32 here
+    for name, got, ref in (("dxa", dxa, src_a.grad), ("dxt", dxt, src_t.grad)):
+        err = (got.float().cpu() - ref).abs().max().item()
+        assert err <= 1.5 * 2 ** -8 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+    for name, got, ref in (("dgamma_a", dga, ga_r.grad), ("dbeta_a", dba, ba_r.grad), ("dgamma_t", dgt, gt_r.grad),
+                           ("dbeta_t", dbt, bt_r.grad)):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,L,Lf,d,masked", [(3, 40, 17, 128, True), (2, 130, 130, 768, False), (4, 9, 4, 256, True)])
+def test_legacy_scalar_gate_kernels_through_c_abi(lib, B, L, Lf, d, masked):
+    """hriemo_masked_mean_fwd, hriemo_rowsum_f32 and hriemo_scalar_gate_dx (models/beta_gate.py:6-32,97-112)."""
+    g = torch.Generator().manual_seed(3000 + L)
+    X = torch.randn(B, L, d, generator=g).bfloat16()
+    m = ragged_mask(B, L, g) if masked else None
+    v = (~m).float() if m is not None else torch.ones(B, L)
+    pooled_r = (X.float() * v[..., None]).sum(1) / v.sum(1).clamp(min=1)[:, None]
+    m_d = m.cuda().view(torch.uint8) if m is not None else None
+    pooled, cnt = f32(B, d), f32(B)
+    X_d = X.cuda()              # device operands live in variables: a temporary inside the argument list is freed (and its
+    lib.call("hriemo_masked_mean_fwd", P(X_d), P(m_d), P(pooled), P(cnt), B, L, d, ST())   # address reused) before the launch
+    assert (pooled.cpu() - pooled_r).abs().max() <= 2e-6 * max(1.0, pooled_r.abs().max().item())
+    assert torch.equal(cnt.cpu(), v.sum(1).clamp(min=1))
+
+    x = torch.randn(B, 777, generator=g)
+    out, x_d = f32(B), x.cuda()
+    lib.call("hriemo_rowsum_f32", P(x_d), P(out), B, 777, ST())
+    assert (out.cpu() - x.sum(1)).abs().max() <= 1e-4
+
+    dH = torch.randn(B, Lf, d, generator=g).bfloat16()
+    beta = torch.sigmoid(torch.randn(B, generator=g))
+    dpool = torch.randn(B, d, generator=g)
+    dH_d, beta_d, dpool_d = dH.cuda(), beta.cuda(), dpool.cuda()
+    for is_a in (1, 0):
+        dX = bf(B, L, d)
+        lib.call("hriemo_scalar_gate_dx", P(dH_d), Lf, P(beta_d), is_a, P(dpool_d), P(cnt), P(m_d), P(dX), B, L, d, ST())
+        coef = beta if is_a else 1 - beta
+        ref = v[..., None] * dpool[:, None, :] / cnt.cpu()[:, None, None]
+        ref[:, :Lf] += coef[:, None, None] * dH.float()
+        assert (dX.float().cpu() - ref).abs().max() <= 2 ** -8 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,p,roff", [(37, 128, 0.1, 0), (384, 2048, 0.1, 12345), (5, 8, 0.5, 7), (64, 3072, 0.0, 0)])
+def test_dropout_kernel_exact_vs_hash_replica(lib, M, N, p, roff):
+    """hriemo_dropout_bf16 (the decoder's mid-FFN dropout, emotion_decoder.py:58): kept elements are x/(1-p) rounded to bf16,
+    dropped ones exactly 0, with the keep mask of the host replica of the counter hash -- bit-exact; applying it twice
+    (forward on h, backward on dh) uses the same mask."""
+    g = torch.Generator().manual_seed(4000 + M)
+    X = torch.randn(M, N, generator=g).bfloat16()
+    seed, site = 2024_10_04, 9
+    Y, X_d = bf(M, N), X.cuda()
+    lib.call("hriemo_dropout_bf16", P(X_d), P(Y), M, N, float(p), seed, None, site, roff, ST())
+    if p == 0.0:
+        assert torch.equal(Y.cpu(), X)
+        return
+    keep = torch.from_numpy(hashrng.rows_mask(seed, site, M, N, p, roff))
+    ref = torch.where(keep, (X.float() * np.float32(hashrng.inv_keep(p))).bfloat16(), torch.zeros((), dtype=torch.bfloat16))
+    assert torch.equal(Y.cpu(), ref)
+    assert abs(float((~keep).float().mean()) - p) < 0.05 + 2.0 / (M * N) ** 0.5
+    # the device seed word is ADDED to the immediate seed (graph replays draw fresh masks): same as seed+delta
+    word = torch.tensor([977], dtype=torch.int64, device="cuda")
+    Y2, Y3 = bf(M, N), bf(M, N)
+    lib.call("hriemo_dropout_bf16", P(X_d), P(Y2), M, N, float(p), seed, P(word), site, roff, ST())
+    lib.call("hriemo_dropout_bf16", P(X_d), P(Y3), M, N, float(p), seed + 977, None, site, roff, ST())
+    assert torch.equal(Y2, Y3) and not torch.equal(Y2, Y)

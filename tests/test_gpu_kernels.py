@@ -202,11 +202,17 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
               seed, ops.seed_word(qd.device).data_ptr(), site, boff, pq.data_ptr(), pkv.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
     assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv)
-    for name, part, full in (("dq", pq, dq), ("dkv", pkv, dkv)):
-        ref = full.float().sum(0).cpu()
+    # the partials are sums of the fp32 values BEFORE their bf16 rounding: compared with the column sums of the fp32 reference
+    # gradients (tolerance: the bf16 P / dS operands of the kernels, summed over B*L rows), and they must be at least as close to
+    # it as the column sums of the stored (rounded) tiles are
+    for name, part, full, ref in (("dq", pq, dq, dq_ref.sum(0)), ("dkv", pkv, dkv, torch.cat([dk_ref, dv_ref], 1).sum(0))):
         got = part.sum(0).cpu()
+        stored = full.float().sum(0).cpu()
         assert not torch.isnan(part).any(), name       # every partial row is written
-        assert (got - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), (name, (got - ref).abs().max())
+        scale = max(1.0, ref.abs().max().item())
+        assert (got - ref).abs().max() <= 2e-2 * scale, (name, (got - ref).abs().max(), scale)
+        assert (got - stored).abs().max() <= 1e-2 * scale, (name, "vs stored tiles", (got - stored).abs().max())
+        assert (got - ref).norm() <= 1.05 * (stored - ref).norm() + 1e-6 * scale, (name, (got - ref).norm(), (stored - ref).norm())
 
 
 def test_attention_all_pad_row_is_nan(ops):
@@ -219,6 +225,10 @@ def test_attention_all_pad_row_is_nan(ops):
     o, lse = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, L, L, hd, kpm.cuda().view(torch.uint8), 0.0, 0, 0, 0)
     o = o.float().cpu().view(B, L, d)
     assert torch.isnan(o[1]).all() and not torch.isnan(o[0]).any()
+    # the exported map agrees with O and with the reference's need_weights=True path: softmax over an all -inf row is NaN
+    probs = ops.attn_probs(q, kv[:, :d], B, H, L, L, hd, kpm.cuda().view(torch.uint8), lse, 0.0, 0, 0, 0).cpu()
+    assert torch.isnan(probs[1]).all() and torch.isfinite(probs[0]).all()
+    assert (probs[0].sum(-1) - 1).abs().max() <= 1e-3
 
 
 # ------------------------------------------------------------------------------------------- add + LN

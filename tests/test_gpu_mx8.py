@@ -1,0 +1,173 @@
+"""GPU suite: the MX-fp8 operand path of BASELINE.json configs[4] ("fp8 MFMA path": d=1024, 4+2 layers, N_e=7).
+
+ * quantiser vs the host emulation (tests/mx8_emul.py): element bytes and scale bytes identical;
+ * scaled-MFMA GEMM with integer operands that the format holds exactly: results EQUAL the integer matmul for every
+   tile configuration, ragged edges, odd step counts, every epilogue -- a transposed or permuted fragment, a scale
+   byte applied to the wrong block, or a wrong k order cannot hide;
+ * GEMM on random data vs the emulated operands multiplied in fp64;
+ * the module at cfg-5 dimensions against the fp32 oracle with the tolerance stated below and the oracle-with-
+   emulated-fp8-operands as the yardstick (same method as the bf16 autocast yardstick)."""
+import pytest
+import torch
+
+from mx8_emul import mx8_dequantize, mx8_quantize, mx8_roundtrip
+from oracle import hri_emo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import hri_emo_amd  # noqa: F401
+    from hri_emo_amd import _ops
+    return _ops
+
+
+def ints(shape, lo=-8, hi=9, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).float()
+
+
+@pytest.mark.parametrize("M,K,src", [(64, 128, "bf16"), (300, 1024, "bf16"), (37, 4096, "bf16"), (1024, 768, "f32"), (8, 32, "f32")])
+def test_quantiser_matches_host_emulation_bitwise(ops, M, K, src):
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2)      # rows of very different magnitude
+    x[0, :32] = 0.0                                                                          # an all-zero block
+    x[min(1, M - 1), 5] = 448.0 * 4                                                          # a block whose maximum sits on a scale boundary
+    if src == "bf16":
+        x = x.bfloat16()
+    q, sc = ops.quant_mx8(x.cuda())
+    q_ref, s_ref = mx8_quantize(x.float())
+    assert torch.equal(q.cpu(), q_ref), (q.cpu() != q_ref).sum()
+    assert sc.shape[0] == K // 32 and sc.shape[1] % 256 == 0 and sc.shape[1] >= M
+    assert torch.equal(sc[:, :M].t().cpu(), s_ref)
+    back = mx8_dequantize(q.cpu(), sc[:, :M].t().cpu())
+    rel = ((back - x.float()).abs() / x.float().abs().amax(-1, keepdim=True).clamp_min(1e-30)).max().item()
+    assert rel <= 2 ** -4, rel                            # e4m3: 3 mantissa bits, and the block maximum never saturates
+
+
+MX_SHAPES = [(256, 128, 128), (200, 136, 256), (128, 384, 384), (1024, 768, 768), (64, 256, 3072), (37 * 8, 8, 128),
+             (130, 2304, 768), (8192, 1024, 1024), (300, 264, 640)]
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1])
+@pytest.mark.parametrize("M,N,K", MX_SHAPES)
+def test_gemm_mx8_exact_on_integer_operands(ops, M, N, K, cfg):
+    """integers in [-8, 8] survive the quantiser exactly (x * 2^-e is an integer with <= 4 significant bits), so the scaled-MFMA
+    result must equal the integer matmul: bf16 output (rounded once), ReLU, and fp32 output."""
+    from hri_emo_amd import _lib
+    L = _lib.lib()
+    L.hriemo_gemm_mx8_force_config(cfg)
+    try:
+        A, W, b = ints((M, K), seed=1), ints((N, K), -6, 7, seed=2), ints((N,), -3, 4, seed=3)
+        # blocks with different maxima -> different scale bytes per (row, k-block)
+        A[:, :32] = A[:, :32].clamp(-2, 2)
+        W[:, 32:64] = W[:, 32:64].clamp(-1, 1)
+        ref = A @ W.t() + b
+        aq, as_ = ops.quant_mx8(A.cuda().bfloat16())
+        wq, ws = ops.quant_mx8(W.cuda())                      # fp32 source, like the weight masters
+        assert torch.equal(mx8_dequantize(aq.cpu(), as_[:, :M].t().cpu()), A)
+        y = ops.linear_fwd_mx8(aq, as_, wq, ws, b.cuda())
+        assert torch.equal(y.float().cpu(), ref.bfloat16().float()), (cfg, (y.float().cpu() - ref.bfloat16().float()).abs().max())
+        yr = ops.linear_fwd_mx8(aq, as_, wq, ws, b.cuda(), relu=True)
+        assert torch.equal(yr.float().cpu(), ref.clamp(min=0).bfloat16().float())
+        yf = ops.linear_fwd_mx8(aq, as_, wq, ws, b.cuda(), out_f32=True)
+        assert torch.equal(yf.cpu(), ref)
+    finally:
+        L.hriemo_gemm_mx8_force_config(-1)
+
+
+def test_gemm_mx8_random_operands_vs_emulated_product(ops):
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 1000, 520, 1024
+    A = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).bfloat16()
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    aq, as_ = ops.quant_mx8(A.cuda())
+    wq, ws = ops.quant_mx8(W.cuda())
+    y = ops.linear_fwd_mx8(aq, as_, wq, ws, b.cuda(), out_f32=True).cpu()
+    Ad, Wd = mx8_roundtrip(A.float()).double(), mx8_roundtrip(W).double()
+    ref = (Ad @ Wd.t() + b.double()).float()
+    assert (y - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item())      # same operands, fp32 accumulation order only
+    true = A.float() @ W.t() + b
+    rel = ((y - true).norm() / true.norm()).item()
+    assert rel <= 6e-2, rel                                                      # what e4m3 operands cost on this product
+
+
+# --------------------------------------------------------------------------------------------- module level
+def _rand_batch(B, Ta, Tt, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    h_a, h_t = torch.randn(B, Ta, d, generator=g), torch.randn(B, Tt, d, generator=g)
+    la = torch.randint(max(1, Ta // 2), Ta + 1, (B,), generator=g)
+    lt = torch.randint(max(1, Tt // 2), Tt + 1, (B,), generator=g)
+    return h_a, h_t, torch.arange(Ta)[None] >= la[:, None], torch.arange(Tt)[None] >= lt[:, None]
+
+
+def _err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / max(1.0, b.abs().max().item())).item()
+
+
+@pytest.mark.parametrize("B,Ta,Tt,d,ne,lf,ld", [(2, 400, 128, 1024, 7, 4, 2),       # BASELINE configs[4] dimensions
+                                                (3, 100, 40, 768, 6, 2, 2), (4, 32, 16, 128, 4, 2, 2)])
+def test_fusion_mx_fp8_vs_oracle_and_emulated_yardstick(ops, B, Ta, Tt, d, ne, lf, ld):
+    """Stated tolerance of the fp8 GEMM mode: max|out - fp32 oracle| <= 6e-2 * max(1, max|ref|) on logits / beta / z, AND
+    within max(5e-3, ...) of the oracle evaluated with the SAME quantiser on both operands of every projection / FFN GEMM
+    (oracle.LINEAR_OPERAND_HOOK = mx8_roundtrip): against that emulated reference only the bf16 storage of the rest of the
+    path is left, so the HIP path must be as close to it as the bf16 mode is to the fp32 oracle.  The yardstick's own
+    distance from the fp32 oracle is printed in the assertion message."""
+    import hri_emo_amd as H
+    torch.manual_seed(1234)
+    kw = dict(d_model=d, num_emotions=ne, n_heads=8, dropout=0.1, num_layers_fusion=lf, num_layers_decoder=ld)
+    ref = O.FusionWithEmotionDecoder(**kw).eval()
+    m = H.FusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().eval()
+    h_a, h_t, m_a, m_t = _rand_batch(B, Ta, Tt, d, 5)
+    with torch.no_grad():
+        out32 = ref(h_a, h_t, m_a, m_t)
+        O.LINEAR_OPERAND_HOOK = mx8_roundtrip
+        try:
+            out8 = ref(h_a, h_t, m_a, m_t)
+        finally:
+            O.LINEAR_OPERAND_HOOK = None
+        H.set_gemm_mode("mx_fp8")
+        try:
+            got = m(h_a.cuda(), h_t.cuda(), m_a.cuda(), m_t.cuda())
+        finally:
+            H.set_gemm_mode("bf16")
+        got16 = m(h_a.cuda(), h_t.cuda(), m_a.cuda(), m_t.cuda())
+    for name, g8, g16, r32, r8 in zip(("logits", "beta", "z"), got, got16, out32, out8):
+        yard = _err(r8, r32)
+        e32, e8 = _err(g8, r32), _err(g8, r8)
+        assert e32 <= 6e-2, (name, "vs fp32 oracle", e32, "yardstick (emulated fp8 oracle vs fp32 oracle)", yard)
+        assert e32 <= max(1e-2, 2.5 * yard), (name, e32, yard)
+        assert e8 <= max(1.5e-2, 0.5 * yard), (name, "vs emulated-fp8 oracle", e8, "yardstick", yard, "bf16 mode", _err(g16, r32))
+        assert not torch.equal(g8.float().cpu(), g16.float().cpu()) or d % 128 != 0, "fp8 mode must actually change the GEMMs"
+
+
+def test_fusion_mx_fp8_trains(ops):
+    """forward on fp8 operands, backward on the bf16 GEMMs: gradients finite and close to the bf16 mode's (straight-through)."""
+    import hri_emo_amd as H
+    torch.manual_seed(7)
+    m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(4, 48, 24, 256, 9)
+    y = (torch.rand(4, 4, generator=torch.Generator().manual_seed(1)) < 0.3).float().cuda()
+    args = (h_a.cuda(), h_t.cuda(), m_a.cuda(), m_t.cuda())
+
+    def grads():
+        m.zero_grad()
+        logits, beta, _ = m(*args)
+        O.train_step_loss(logits, beta, y).backward()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    g16 = grads()
+    H.set_gemm_mode("mx_fp8")
+    try:
+        g8 = grads()
+    finally:
+        H.set_gemm_mode("bf16")
+    rels = sorted(((g8[n] - g16[n]).norm() / g16[n].norm().clamp_min(1e-30)).item() for n in g16)
+    assert all(torch.isfinite(v).all() for v in g8.values())
+    assert rels[len(rels) // 2] <= 0.15 and rels[-1] <= 1.0, (rels[len(rels) // 2], rels[-3:])

@@ -79,6 +79,31 @@ def test_fusion_attention_maps_vs_golden(H, name, d, ne):
     close(w.sum(-1), torch.ones(w.shape[:-1]), 5e-3, "rows sum to one")
 
 
+def test_attention_maps_default_init_within_1e_2(H):
+    """north_star's bf16 tolerance (1e-2) on the exported attention maps, shown on a benign case: default torch init (softmax
+    not saturated), d=768 / head_dim 96, ragged masks; HIP maps vs the fp32 oracle's, every layer, every map."""
+    torch.manual_seed(1234)
+    kw = dict(d_model=768, num_emotions=6, n_heads=8, dropout=0.1)
+    ref = O.FusionWithEmotionDecoder(**kw).eval()
+    m = H.FusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().eval()
+    h_a, h_t, m_a, m_t = _rand_batch(2, 100, 40, 768, 17)
+    with torch.no_grad():
+        lr, br, zr, pr = ref(h_a, h_t, m_a, m_t, return_attention=True)
+        lg, bg, zg, pg = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t), return_attention=True)
+    close(lg, lr, what="logits"); close(zg, zr, what="z")
+    worst = 0.0
+    for li, (mg, mr) in enumerate(zip(pg["encoder"], pr["encoder"])):
+        for k in mr:
+            worst = max(worst, (mg[k].float().cpu() - mr[k]).abs().max().item())
+            close(mg[k], mr[k], 1e-2, what=f"enc.{li}.{k}")
+    for li, (vg, vr) in enumerate(zip(pg["decoder"], pr["decoder"])):
+        worst = max(worst, (vg.float().cpu() - vr).abs().max().item())
+        close(vg, vr, 1e-2, what=f"dec.{li}")
+    assert worst <= 1e-2, worst
+
+
 def test_fusion_allpad_row_nan_only_for_that_sample(H):
     g = load_golden("cfg1_eval_allpad_row")
     m = fusion(H, 128, 4).eval()
@@ -111,16 +136,39 @@ def _train_step(model, h_a, h_t, m_a, m_t, y, autocast_cpu=False):
     return loss.detach(), logits.detach(), h_a.grad, h_t.grad, grads
 
 
+GRAD_FLOOR = 4e-2          # relative L2 error any bf16 backward may show on a well-conditioned parameter
+GRAD_FACTOR = 3.0          # ... or this many times the reference path's own bf16 (CPU autocast) error on THAT parameter
+
+
+def assert_per_parameter_grads(gm, gy, gr, exceptions=(), what=""):
+    """EVERY parameter n: rel-L2(mine[n], fp32 oracle[n]) <= max(floor, GRAD_FACTOR * rel-L2(yardstick[n], fp32 oracle[n])),
+    the yardstick being the reference path itself in bf16 (torch CPU autocast of the oracle on the same weights).
+    floor = max(GRAD_FLOOR, 90th percentile of the yardstick's own per-parameter errors): with well-conditioned (default
+    init) weights that is 4e-2; with the ill-conditioned closed-form fixture weights the reference-in-bf16 itself is 5-9 %
+    off on most parameters and the floor follows it.  No parameter is exempt unless named in `exceptions` (name -> bound)."""
+    exceptions = dict(exceptions)
+    ys = sorted(_rel(gy[n], gr[n]) for n in gr)
+    floor = max(GRAD_FLOOR, ys[len(ys) * 9 // 10])
+    rows, bad = [], []
+    for n in gr:
+        em, ey = _rel(gm[n], gr[n]), _rel(gy[n], gr[n])
+        bound = exceptions.get(n, max(floor, GRAD_FACTOR * ey))
+        rows.append((em, ey, n))
+        if not em <= bound:
+            bad.append((n, round(em, 4), round(ey, 4), round(bound, 4)))
+    rows.sort(reverse=True)
+    assert not bad, (what, "floor", floor, "parameters over their bound (name, mine, yardstick, bound):", bad, "worst five:", rows[:5])
+    return rows
+
+
 @pytest.mark.parametrize("name,d,ne,init", [("cfg1_train_p0", 128, 4, "closed"), ("hd96_train_p0", 768, 6, "closed"),
                                             ("cfg1_train_p0", 128, 4, "random"), ("hd96_train_p0", 768, 6, "random")])
 def test_fusion_train_step_grads(H, name, d, ne, init):
     """fwd+bwd of the trainer's step (train_fusion_seq_level_decoder.py:310-331, dropout=0) on the golden
     inputs.  Gradient accuracy of a bf16 path depends on the conditioning of the weights, so the bound is
     the reference path itself evaluated in bf16: torch's CPU autocast(bfloat16) of the oracle on the same
-    weights is the yardstick; per-parameter relative L2 errors (vs the fp32 oracle) must stay within
-    2x of the yardstick's median and 90th percentile over the parameters (floors 2e-2 / 1e-1).  The
-    maximum is not bounded: a ReLU unit of the tiny gate MLP whose pre-activation is ~0 flips under any
-    rounding (the yardstick itself shows 100 % error on beta_gate.mlp.0 with the fixture weights).  With
+    weights is the yardstick, and EVERY parameter's relative L2 error (vs the fp32 oracle) must stay within
+    max(4e-2, 3x the yardstick's error on that same parameter) -- see assert_per_parameter_grads.  With
     the closed-form fixture weights the fp32 oracle's loss/logits/grad norms are additionally the
     committed golden values."""
     g = load_golden(name)
@@ -142,12 +190,27 @@ def test_fusion_train_step_grads(H, name, d, ne, init):
     close(loss_m.reshape(1), loss_r.reshape(1), what="loss"); close(logits_m, logits_r, what="logits")
     for n, p in m.named_parameters():
         assert p.grad.dtype == torch.float32 and p.grad.shape == p.shape, n
-    mine = sorted((_rel(gm[n], gr[n]), n) for n in gr)
-    yard = sorted((_rel(gy[n], gr[n]), n) for n in gr)
-    med_m, med_y = mine[len(mine) // 2][0], yard[len(yard) // 2][0]
-    p90_m, p90_y = mine[len(mine) * 9 // 10][0], yard[len(yard) * 9 // 10][0]
-    assert med_m <= max(2e-2, 2.0 * med_y), (med_m, med_y, mine[-3:])
-    assert p90_m <= max(1e-1, 2.0 * p90_y), (p90_m, p90_y, mine[-3:], yard[-3:])
+    assert_per_parameter_grads(gm, gy, gr, what=f"{name}/{init}")
+    assert _rel(ga_m, ga_r) <= max(3e-2, 1.5 * _rel(ga_y, ga_r)), "d loss / d h_a"
+    assert _rel(gt_m, gt_r) <= max(3e-2, 1.5 * _rel(gt_y, gt_r)), "d loss / d h_t"
+
+
+def test_fusion_train_step_grads_cfg2_shape(H):
+    """The same per-parameter gradient bound at the HEADLINE shape (BASELINE configs[1]: d=768, T_a=400, T_t=128, N_e=6,
+    H=8, 2+2 layers; B=2 keeps the CPU oracle and its autocast yardstick within seconds), default torch init, ragged masks."""
+    torch.manual_seed(1234)
+    kw = dict(d_model=768, num_emotions=6, n_heads=8, dropout=0.0)
+    ref = O.FusionWithEmotionDecoder(**kw).train()
+    m = H.FusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(2, 400, 128, 768, 41)
+    y = (torch.rand(2, 6, generator=torch.Generator().manual_seed(42)) < 0.3).float()
+    loss_r, logits_r, ga_r, gt_r, gr = _train_step(ref, h_a, h_t, m_a, m_t, y)
+    _, _, ga_y, gt_y, gy = _train_step(ref, h_a, h_t, m_a, m_t, y, autocast_cpu=True)
+    loss_m, logits_m, ga_m, gt_m, gm = _train_step(m, cu(h_a), cu(h_t), cu(m_a), cu(m_t), cu(y))
+    close(loss_m.reshape(1), loss_r.reshape(1), what="loss"); close(logits_m, logits_r, what="logits")
+    assert_per_parameter_grads(gm, gy, gr, what="cfg2 shape")
     assert _rel(ga_m, ga_r) <= max(3e-2, 1.5 * _rel(ga_y, ga_r)), "d loss / d h_a"
     assert _rel(gt_m, gt_r) <= max(3e-2, 1.5 * _rel(gt_y, gt_r)), "d loss / d h_t"
 
@@ -194,6 +257,7 @@ def _rand_batch(B, Ta, Tt, d, seed, ragged=True):
 
 @pytest.mark.parametrize("B,Ta,Tt,d,ne,lf,ld", [
     (3, 100, 40, 768, 6, 2, 2), (2, 130, 50, 256, 7, 2, 2), (4, 32, 16, 128, 4, 2, 2),
+    (2, 400, 128, 768, 6, 2, 2),          # BASELINE configs[1]/[2]: THE headline shape (IEMOCAP seq-level), per-GPU shard of cfg 3
     (2, 1000, 50, 768, 6, 2, 2),          # BASELINE configs[3]: MOSEI shape, long asymmetric cross-attention
     (2, 400, 128, 1024, 7, 4, 2),         # BASELINE configs[4] dimensions (d=1024 -> head_dim 128, 4+2 layers), bf16 path
     (2, 64, 64, 512, 5, 1, 1),            # L_a == L_t (no truncation in the gate), head_dim 64, 1+1 layers
@@ -396,10 +460,17 @@ def test_mosei_wrapper_vs_golden_and_amp_gradscaler(H):
     loss = O.train_step_loss(l2, b2, cu(g["y"]))
     loss.backward()
     close(loss.reshape(1), g["loss"], what="loss")
+    # yardstick rule (assert_per_parameter_grads): the oracle's own CPU-autocast(bf16) error on the same parameter
+    refy = O.closed_form_init_(O.MoseiFusionWithEmotionDecoder(d_audio=74, d_text=300, dropout=0.0)).train()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ly, by, _ = refy(g["h_a"], g["h_t"], g["mask_a"], g["mask_t"])
+    O.train_step_loss(ly.float(), by.float(), g["y"]).backward()
+    gyard = {n: p.grad for n, p in refy.named_parameters()}
     for name, key in (("audio_proj.weight", "g_audio_proj_w"), ("audio_proj.bias", "g_audio_proj_b"),
                       ("text_proj.weight", "g_text_proj_w"), ("text_proj.bias", "g_text_proj_b")):
         got = dict(mt.named_parameters())[name].grad
-        assert _rel(got, g[key]) <= 0.15, (name, _rel(got, g[key]))       # bf16 backward on the fixture weights
+        em, ey = _rel(got, g[key]), _rel(gyard[name], g[key])
+        assert em <= max(GRAD_FLOOR, GRAD_FACTOR * ey), (name, em, ey)
     # AMP + GradScaler step
     opt = torch.optim.AdamW(mt.parameters(), lr=1e-4)
     scaler = torch.amp.GradScaler("cuda")
@@ -525,6 +596,43 @@ def test_fused_clip_adamw_matches_torch(H):
     # the model still runs on the re-homed parameter storage
     with torch.no_grad():
         m.eval()(cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+
+
+def test_eager_steps_with_fused_optimizer_follow_torch_adamw(H):
+    """Eager (no hipGraph) DataParallelStep + FusedClipAdamW for several steps against the same model driven by
+    clip_grad_norm_ + torch.optim.AdamW: the fused optimizer rewrites the flat parameter buffer through raw pointers, so the
+    bf16 weight shadows must be told (WEIGHTS_EPOCH) -- otherwise every forward after the first runs on the initial weights.
+    lr is large so a stale-weights forward shows up in the very next loss."""
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.optim import FusedClipAdamW
+    from hri_emo_amd.train import fusion_step_loss
+    g = load_golden("cfg1_train_p0")
+    batch = (cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]), cu(g["y"]))
+    torch.manual_seed(9)
+    m1 = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    m2 = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0)
+    m2.load_state_dict(m1.state_dict())
+    m2.cuda().train()
+    dp = DataParallelStep(m1, fusion_step_loss, overlap=False)
+    opt1 = FusedClipAdamW(dp.buckets, lr=3e-3, weight_decay=1e-2, max_norm=5.0)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=3e-3, weight_decay=1e-2)
+    l1s, l2s = [], []
+    for step in range(4):
+        l1s.append(float(dp.step(*batch)))                       # eager: zero-grad + fwd + loss + bwd
+        opt1.step()
+        opt2.zero_grad(set_to_none=True)
+        logits, beta, _ = m2(*batch[:4])
+        loss2 = fusion_step_loss(logits, beta, batch[4])
+        loss2.backward()
+        torch.nn.utils.clip_grad_norm_(m2.parameters(), 5.0)
+        opt2.step()
+        l2s.append(float(loss2))
+    assert abs(l1s[1] - l1s[0]) > 1e-3 and abs(l1s[3] - l1s[2]) > 1e-4, ("the updates must be visible in the loss", l1s)
+    for a, b in zip(l1s, l2s):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (l1s, l2s)
+    with torch.no_grad():
+        o1, o2 = m1.eval()(*batch[:4]), m2.eval()(*batch[:4])
+    close(o1[0], o2[0], 5e-3, "logits after 4 steps")
 
 
 def test_trimmed_batch_gives_the_same_outputs(H):
