@@ -17,9 +17,11 @@ _SIGS = {
     "hriemo_quant_mx8": ("pliiiplplp", "i"),
     "hriemo_gemm_mx8": ("iiiplplplplplipiplp", "i"),
     "hriemo_gemm_mx8_force_config": ("i", "i"),
-    "hriemo_attn_fwd": ("plplplplppiiiiifQpIip", "i"),
-    "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIippp", "i"),
+    "hriemo_attn_fwd": ("plplplplppiiiiifQpIipp", "i"),
+    "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIipppp", "i"),
+    "hriemo_attn_mask_bytes": ("iiii", "l"),
     "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),
+    "hriemo_attn_bwd_dq_colsum_rows": ("iiiii", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),

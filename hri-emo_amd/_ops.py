@@ -408,34 +408,47 @@ def _in_backward():
         return False
 
 
-def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off):
+def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=False):
+    """-> (o, lse) or, with want_bits, (o, lse, mask_bits|None): the dropout keep-mask as bit words for the backward"""
     o = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    mb = None
+    if want_bits and p > 0:
+        mb = torch.empty(_lib.lib().hriemo_attn_mask_bytes(B, H, Lq, Lk) // 8, dtype=torch.int64, device=q.device)
     _lib.call("hriemo_attn_fwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-              _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _stream())
-    return o, lse
+              _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _p(mb), _stream())
+    return (o, lse, mb) if want_bits else (o, lse)
 
 
-def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None):
-    """bias_grad = (db_q [d], db_kv [2d]) fp32 views to ACCUMULATE the column sums of dQ and dK|dV into: the kernels
-    leave per-wave partial sums behind and the launch-boundary reduce adds them up (no pass over dQ/dK/dV).
-    Returns True if it took care of them."""
+def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None, mask_bits=None):
+    """bias_grad = (db_q [d], db_kv [2d]) fp32 views the column sums of dQ and dK|dV go to: the kernels leave per-block partial
+    sums behind (fp32 values before the bf16 rounding of dQ/dK/dV); inside backward with the fused path they are finished by the
+    launch-boundary reduce (accumulating), otherwise by one reduce launch right here (overwriting).  Returns True if it took
+    care of them."""
     delta = torch.empty_like(lse)
     pq = pkv = None
-    fold = bias_grad is not None and DEFER_REDUCE and FOLD_ATTN_BIAS and _in_backward()
+    fold = bias_grad is not None and FOLD_ATTN_BIAS
     if fold:
         L_ = _lib.lib()
-        rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, H, Lq, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
+        rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
         pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
         pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
     _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
               _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
               _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
-              _p(pq), _p(pkv), _stream())
+              _p(pq), _p(pkv), _p(mask_bits), _stream())
     if fold:
         d = H * hd
-        _deferred.add(pq, d, rq, d, 1, [bias_grad[0]], True)
-        _deferred.add(pkv, 2 * d, rk, 2 * d, 1, [bias_grad[1]], True)
+        deferred = bias_grad[2] if len(bias_grad) > 2 else False
+        if deferred and DEFER_REDUCE and _in_backward():
+            _deferred.add(pq, d, rq, d, 1, [bias_grad[0]], True)
+            _deferred.add(pkv, 2 * d, rk, 2 * d, 1, [bias_grad[1]], True)
+        else:
+            red = _DeferredReduce()
+            red.device = q.device
+            red.add(pq, d, rq, d, 1, [bias_grad[0]], deferred, schedule=False)
+            red.add(pkv, 2 * d, rk, 2 * d, 1, [bias_grad[1]], deferred, schedule=False)
+            red.flush()
     return fold
 
 
@@ -511,7 +524,7 @@ class _DeferredReduce:
         self.hooks.append((hook, p))
         self._schedule()
 
-    def add(self, part, pstride, np_, w, nseg, outs, accumulate):
+    def add(self, part, pstride, np_, w, nseg, outs, accumulate, schedule=True):
         gx = (w + 31) // 32
         self.jobs.append([part.data_ptr(), pstride, np_, w, nseg | (int(bool(accumulate)) << 8) | (self.blocks << 32)]
                          + [o.data_ptr() for o in outs] + [0] * (3 - len(outs)))
@@ -519,7 +532,8 @@ class _DeferredReduce:
         self.keep.append(part)
         self.keep.extend(outs)
         self.device = part.device
-        self._schedule()
+        if schedule:
+            self._schedule()
 
     def flush(self):
         jobs, n, nblocks = self.jobs, len(self.jobs), self.blocks
@@ -600,11 +614,11 @@ class SelfAttnLN(torch.autograd.Function):
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         qkv = proj_fwd(x2, sh, w_in, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        o, lse = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off)
+        o, lse, mbits = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off, want_bits=True)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
-        ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
+        ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
@@ -612,7 +626,7 @@ class SelfAttnLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
-        x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
+        x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, L, d, H, hd, p, seed, site, b_off = ctx.cfg
         M = B * L
         dev = x2.device
@@ -629,7 +643,7 @@ class SelfAttnLN(torch.autograd.Function):
         dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
         db_in = sink.buf(p_b_in)
         folded = attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                          lse, B, H, L, L, hd, kpm, p, seed, site, b_off, bias_grad=(db_in[:d], db_in[d:]) if acc else None)
+                          lse, B, H, L, L, hd, kpm, p, seed, site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits)
         dw_in = sink.buf(p_w_in)
         linear_dw(dqkv, x2, dw_in, acc)
         if not folded:
@@ -659,11 +673,11 @@ class CrossAttnLN(torch.autograd.Function):
         q = proj_fwd(xq2, sh, w_in, w_in16, b_in, rows=(0, d))
         kv = proj_fwd(xkv2, sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
-        o, lse = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off)
+        o, lse, mbits = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=True)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN)
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
-        ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm)
+        ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
@@ -671,7 +685,7 @@ class CrossAttnLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
-        xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm = ctx.saved_tensors
+        xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
         dev = xq2.device
         dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(B * Lq, d)
@@ -688,7 +702,7 @@ class CrossAttnLN(torch.autograd.Function):
         dkv = torch.empty((B * Lk, 2 * d), dtype=BF16, device=dev)
         db_in = sink.buf(p_b_in)
         folded = attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm, p, seed,
-                          site, b_off, bias_grad=(db_in[:d], db_in[d:]) if acc else None)
+                          site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits)
         dw_in = sink.buf(p_w_in)
         linear_dw(dq, xq2, dw_in[:d], acc)
         linear_dw(dkv, xkv2, dw_in[d:], acc)

@@ -37,6 +37,11 @@ struct AttnArgs {
   float scale;
   uint32_t thr16; float inv_keep; uint64_t seed; uint32_t site; int b_offset;
   const unsigned long long* seed_dev;
+  // Dropout keep-mask as BITS, written once by the forward and read by both backward kernels instead of re-hashing
+  // (3.3 MB per cross-attention site at cfg 2 against ~7 VALU operations per element and kernel).  One 64-bit word per
+  // (batch, head, query, 64-key tile): bit 16*g + 4*n + r  <->  key 64*tile + 16*n + 4*g + r (the forward's register order:
+  // lane group g holds keys 4g..4g+3 of each 16-key subtile n).  NULL: the backward replays the hash.
+  unsigned long long* mbits;
 };
 
 // v_exp_f32 directly: arguments are <= 0 (or -inf), no denormal-range fix-up needed
@@ -279,14 +284,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
         // keys 4g..4g+3 of each 16-key subtile = two hash pairs; one multiply-free step per extra pair.  The
         // 1/(1-p) factor of the kept probabilities is applied once, to O, after the last key tile.
         const uint32_t hb = drop_base(key32, (uint32_t)(qbase + qs * 16 + i), (uint32_t)((kt * 64 + 4 * g) >> 1));
+        uint32_t bits = 0u;
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
             const uint32_t x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
-            s[qs][n][2 * pr] = keep_lo(x, a.thr16) ? s[qs][n][2 * pr] : 0.f;
-            s[qs][n][2 * pr + 1] = keep_hi(x, a.thr16) ? s[qs][n][2 * pr + 1] : 0.f;
+            const bool k0 = keep_lo(x, a.thr16), k1 = keep_hi(x, a.thr16);
+            s[qs][n][2 * pr] = k0 ? s[qs][n][2 * pr] : 0.f;
+            s[qs][n][2 * pr + 1] = k1 ? s[qs][n][2 * pr + 1] : 0.f;
+            bits |= (k0 ? 1u : 0u) << (n * 4 + 2 * pr) | (k1 ? 1u : 0u) << (n * 4 + 2 * pr + 1);
           }
+        if (a.mbits != nullptr && qbase + qs * 16 + i < a.Lq)       // this lane's 16 bits of the (query, key tile) word
+          ((unsigned short*)(a.mbits + (((long)bh * a.Lq + qbase + qs * 16 + i) * nkt + kt)))[g] = (unsigned short)bits;
       }
     }
 
@@ -350,7 +360,7 @@ __device__ __forceinline__ void block_colsum_store(f32x4 (&cs)[DT], float* red, 
 }
 
 // ------------------------------------------------------------------------------------------ dQ (+ delta)
-template <int HD, int NW, int QW>
+template <int HD, int NW, int QW, bool BITS>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
@@ -463,13 +473,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 #pragma unroll
     for (int qs = 0; qs < QW; ++qs) {
       const uint32_t hb = drop_base(key32, (uint32_t)(qbase + qs * 16 + i), (uint32_t)((kt * 64 + 4 * g) >> 1));
+      uint32_t bits = 0xffffu;                            // dropout off: everything kept
+      constexpr bool from_bits = BITS;
+      if (from_bits && a.thr16 != 0)                      // same register order as the forward: this lane's own 16 bits
+        bits = ((const unsigned short*)(a.mbits + (((long)bh * a.Lq + min(qbase + qs * 16 + i, a.Lq - 1)) * nkt + kt)))[g];
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           uint32_t x = 0xffffffffu;                       // dropout off: both halves >= any threshold
-          if (a.thr16 != 0) x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
+          if (a.thr16 != 0 && !from_bits) x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const int r = 2 * pr + e;
@@ -477,7 +491,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
             // (1 - p_drop), so dS = pk * (keep ? dP : 0  -  delta') is one fma + exp + select + sub + mul
             const float pk = EXP2(fmaf(s[qs][n][r], sl2, bias[r] + cexp[qs]));
             float dpd = dp[qs][n][r];
-            if (a.thr16 != 0) dpd = (e ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16)) ? dpd : 0.f;
+            if (a.thr16 != 0) {
+              const bool keep = from_bits ? ((bits >> (n * 4 + r)) & 1u) != 0u : (e ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16));
+              dpd = keep ? dpd : 0.f;
+            }
             s[qs][n][r] = pk * (dpd - dlk[qs]);
           }
         }
@@ -524,24 +541,42 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
   }
 }
 
-// ------------------------------------------------------------------------------------------ dK, dV
-template <int HD, int NW, int KW, int QT>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a) {
+// ------------------------------------------------------------------------------------------ dK, dV (+ dQ when fused)
+// One block = NW waves x KW 16-key sub-tiles = NK keys of one (batch, head), swept over all queries in tiles of QT rows.
+// Keys sit on the lanes (S = Q.K^T un-transposed), so P and dS are already the B operands of dV^T += dO^T.P and
+// dK^T += Q^T.dS; dK and dV of the block's keys live in registers for the whole sweep (no atomics, deterministic).
+//   BITS : the dropout keep-mask comes from the forward's bit words (AttnArgs::mbits) instead of the hash
+//   FUSED: the block holds ALL keys of its (batch, head) (L_k <= NK), so dQ is complete inside the block too and the
+//          separate dQ kernel (which recomputes S and dP: 7 GEMMs per tile instead of 5, Q/K/V/dO read twice) is not
+//          launched.  dS crosses LDS once, transposed ([key][query] bf16, 8-byte stores); every wave then multiplies a
+//          [16 query x HD/2] slice of dQ = dS.K over all NK keys (K^T fragments by transposed reads of the block's K tile)
+//          and stores it.  delta = rowsum(dO * O) is computed here as well (8 lanes per query row).
+// Per query row the Q image's 32 pad bytes carry the row's sideband: {lse', delta', keep-mask dwords [tile][half]}.
+template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED>
+__global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
-  static_assert(QT == 32 || QT == 64, "query tile");
+  static_assert(QT == 32, "query tile");
+  static_assert(!FUSED || (NW == 4 && DT % 2 == 0), "fused dQ: 4 waves, each a [16 x HD/2] slice");
+  constexpr int DH = FUSED ? DT / 2 : 1;             // output tiles per wave of the fused dQ
   constexpr int NQS = QT / 16, NKQ = QT / 32;
-  // two LDS images of the (Q, dO, lse, delta) tile: the next tile is committed while the current one is consumed,
-  // so a query tile costs ONE barrier instead of two and the LDS stores overlap the MFMAs
-  constexpr int TILE_BYTES = 2 * QT * STRIDE + 2 * QT * 4;
-  __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+  constexpr int NK = NW * KW * 16;                   // keys per block
+  constexpr int NKTB = (NK + 63) / 64;               // 64-key tiles (mask words) a block touches
+  constexpr int SB = G::HDP * 2;                     // sideband offset inside a Q-image row (its 32 pad bytes)
+  static_assert(STRIDE - SB >= 8 + 8 * NKTB, "sideband must fit the pad bytes");
+  constexpr int IMG = 2 * QT * STRIDE;               // Q image + dO image
+  constexpr int DSS = QT * 2 + 32;                   // row stride of the dS^T tile ([key][QT queries] bf16)
+  constexpr int KT_BYTES = FUSED ? NK * STRIDE : 0, DST_BYTES = FUSED ? NK * DSS : 0;
+  __shared__ __attribute__((aligned(16))) char lds[2 * IMG + KT_BYTES + 2 * DST_BYTES];
+  char* const Ktile = lds + 2 * IMG;
+  char* const dSt0 = Ktile + KT_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
-  tile_and_head((a.Lk + NW * KW * 16 - 1) / (NW * KW * 16), a.B * a.H, tile, bh);
+  tile_and_head((a.Lk + NK - 1) / NK, a.B * a.H, tile, bh);
   const int b = bh / a.H, h = bh - b * a.H;
-  const int kbase = tile * (NW * KW * 16) + wave * KW * 16;
+  const int kbase = tile * NK + wave * KW * 16;
 
-  bf16x8 kreg[KW][KS], vreg[KW][KS];
+  bf16x8 kreg[FUSED ? 1 : KW][FUSED ? 1 : KS], vreg[KW][KS];
   bool kvalid[KW];
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw) {
@@ -553,13 +588,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int e = ks * 32 + 8 * g;
-      kreg[kw][ks] = (e < HD) ? *(const bf16x8*)(kp + e) : zero8();
+      if (!FUSED) kreg[kw][ks] = (e < HD) ? *(const bf16x8*)(kp + e) : zero8();    // fused: read from the block's K tile in LDS
       vreg[kw][ks] = (e < HD) ? *(const bf16x8*)(vp + e) : zero8();
     }
   }
-  uint32_t hkb[KW];                     // hash base of this lane's key: key32 + (key>>1)*CB  (a-term added per query)
-#pragma unroll
-  for (int kw = 0; kw < KW; ++kw) hkb[kw] = 0u;
+  if (FUSED) load_tile<HD, NK, NT>(Ktile, a.K + (long)b * a.Lk * a.ldk + h * HD, a.ldk, 0, a.Lk, tid);    // rows >= L_k zero
   f32x4 dk[KW][DT], dv[KW][DT];
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw)
@@ -570,47 +603,96 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
     }
   const float sl2 = a.scale * LOG2E;
   const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+  uint32_t hkb[KW];                     // hash base of this lane's key: key32 + (key>>1)*CB  (a-term added per query)
+  int mbit[KW];                         // BITS: bit of this lane's key inside its mask dword, and which dword of the sideband
 #pragma unroll
-  for (int kw = 0; kw < KW; ++kw) hkb[kw] = drop_base(key32, 0u, (uint32_t)((kbase + kw * 16 + i) >> 1));
+  for (int kw = 0; kw < KW; ++kw) {
+    hkb[kw] = drop_base(key32, 0u, (uint32_t)((kbase + kw * 16 + i) >> 1));
+    const int kloc = (kbase + kw * 16) & 63;        // 16-key subtile n = kloc / 16 of its 64-key tile
+    mbit[kw] = ((i >> 2) * 16 + (kloc >> 4) * 4 + (i & 3)) & 31;
+  }
+  // sideband dword of this lane: tile (kbase relative to the block's first key) and half (i >= 8); the same for every kw of
+  // a wave when KW <= 2 (a wave's 32 keys never straddle a 64-key tile)
+  const int mdw = 2 + (((kbase - tile * NK) >> 6) * 2 + (i >> 3));
+  const int nkt_all = (a.Lk + 63) >> 6, kt0 = (tile * NK) >> 6;
   const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
   const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
+  const bf16_t* Ob = a.O + (long)b * a.Lq * a.ldo + h * HD;
   const long lbase = ((long)b * a.H + h) * a.Lq;
   const int nqt = (a.Lq + QT - 1) / QT;
 
   const float l2ik = a.thr16 != 0 ? log2f(a.inv_keep) : 0.f, keepfrac = a.thr16 != 0 ? 1.f / a.inv_keep : 1.f;
-  constexpr bool PF = (NW == 4);
   TileRegs<HD, QT, NT> qr, dor;
-  float lse_r = 0.f, del_r = 0.f;                 // lse / delta of query row `tid` of the tile in flight (tid < QT)
+  // sideband of query row `tid` of the tile in flight (threads tid < QT): lse', delta' (not fused), mask words
+  float lse_r = 0.f, del_r = 0.f;
+  unsigned long long mw_r[NKTB];
+  // fused: delta = rowsum(dO * O), 8 threads per row (thread t: row t / 8, elements (t & 7) * HD/8 .. + HD/8).  The loads for
+  // tile j+2 are issued at the top of iteration j and reduced right after its S / dP MFMAs (12 registers live only there); the
+  // sum travels in one register to commit(j+2) at the top of iteration j+1.
+  constexpr int EPT = HD / 8;
+  float del_part = 0.f;
+  auto delta_of = [&](int qt) -> float {
+    const int q = min(qt * QT + (tid >> 3), a.Lq - 1);
+    const bf16_t* dp_ = dOb + (long)q * a.lddo + (tid & 7) * EPT;
+    const bf16_t* op_ = Ob + (long)q * a.ldo + (tid & 7) * EPT;
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT / 2; ++e) {
+      const bf16x2 x = *(const bf16x2*)(dp_ + 2 * e), y = *(const bf16x2*)(op_ + 2 * e);
+      part += (float)x[0] * (float)y[0] + (float)x[1] * (float)y[1];
+    }
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    return part * keepfrac;
+  };
   auto fetch = [&](int qt) {
     tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, qt * QT, a.Lq, tid);
     tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, qt * QT, a.Lq, tid);
     if (tid < QT) {
       const int q = qt * QT + tid;
       lse_r = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
-      del_r = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
+      if (!FUSED) del_r = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
+      if (BITS) {
+#pragma unroll
+        for (int t = 0; t < NKTB; ++t)
+          mw_r[t] = (q < a.Lq && kt0 + t < nkt_all) ? a.mbits[(lbase + q) * nkt_all + kt0 + t] : 0ull;
+      }
     }
   };
   auto commit = [&](int buf) {
-    char* base = lds + buf * TILE_BYTES;
+    char* base = lds + buf * IMG;
     tile_commit<HD, QT, NT>(qr, base, tid);
     tile_commit<HD, QT, NT>(dor, base + QT * STRIDE, tid);
     if (tid < QT) {
-      ((float*)(base + 2 * QT * STRIDE))[tid] = lse_r;
-      ((float*)(base + 2 * QT * STRIDE))[QT + tid] = del_r;
+      char* sb = base + tid * STRIDE + SB;
+      *(LDS_PTR(float))(sb) = lse_r;
+      if (!FUSED) *(LDS_PTR(float))(sb + 4) = del_r;
+      if (BITS) {
+#pragma unroll
+        for (int t = 0; t < NKTB; ++t) {
+          *(LDS_PTR(unsigned))(sb + 8 + 8 * t) = (unsigned)mw_r[t];
+          *(LDS_PTR(unsigned))(sb + 12 + 8 * t) = (unsigned)(mw_r[t] >> 32);
+        }
+      }
     }
+    if (FUSED && (tid & 7) == 0) *(LDS_PTR(float))(base + (tid >> 3) * STRIDE + SB + 4) = del_part;
   };
   fetch(0);
+  if (FUSED) del_part = delta_of(0);
   commit(0);
-  if (nqt > 1) fetch(1);
+  if (nqt > 1) { fetch(1); if (FUSED) del_part = delta_of(1); }
   __syncthreads();
+  // fused: colsum(dQ) = (sum over queries of dS) . K -- one running sum per key instead of accumulators over the dQ slices
+  float dsum[KW];
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) dsum[kw] = 0.f;
   for (int qt = 0; qt < nqt; ++qt) {
-    const char* Qt = lds + (qt & 1) * TILE_BYTES;
+    const char* Qt = lds + (qt & 1) * IMG;
     const char* dOt = Qt + QT * STRIDE;
-    const float* lse_s = (const float*)(Qt + 2 * QT * STRIDE);
-    const float* del_s = lse_s + QT;
     if (qt + 1 < nqt) {
       commit((qt + 1) & 1);                       // image last read in iteration qt-1, released by its closing barrier
-      if (qt + 2 < nqt) fetch(qt + 2);
+      if (qt + 2 < nqt) { fetch(qt + 2); if (FUSED) del_part = delta_of(qt + 2); }
     }
 
     f32x4 s[KW][NQS], dp[KW][NQS];
@@ -629,34 +711,57 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
         const bf16x8 dofr = row_frag(dOt, STRIDE, qs * 16 + i, ks * 4 + g);
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
-          s[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kreg[kw][ks], s[kw][qs], 0, 0, 0);
+          bf16x8 kf;
+          if constexpr (FUSED) kf = row_frag(Ktile, STRIDE, wave * KW * 16 + kw * 16 + i, ks * 4 + g);
+          else kf = kreg[kw][ks];
+          s[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf, s[kw][qs], 0, 0, 0);
           dp[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vreg[kw][ks], dp[kw][qs], 0, 0, 0);
         }
       }
     bf16x8 pf[KW][NKQ], dsf[KW][NKQ];
+    char* const dSt = dSt0 + (qt & 1) * DST_BYTES;
 #pragma unroll
     for (int qs = 0; qs < NQS; ++qs) {
-      // lse_s holds (log2(1/(1-p_drop)) - lse*log2e), del_s holds delta*(1-p_drop): pk = p/(1-p_drop) straight
-      // from the exponent, P~ = keep ? pk : 0, dS = pk * (keep ? dP : 0  -  delta')
-      const f32x4 lse4 = *(LDS_PTR(const f32x4))(lse_s + qs * 16 + 4 * g);
-      const f32x4 del4 = *(LDS_PTR(const f32x4))(del_s + qs * 16 + 4 * g);
+      // sideband of query rows qs*16 + 4g + r: lse' = log2(1/(1-p_drop)) - lse*log2e, delta' = delta*(1-p_drop): pk = p/(1-p_drop)
+      // straight from the exponent, P~ = keep ? pk : 0, dS = pk * (keep ? dP : 0  -  delta')
+      float lse4[4], del4[4];
+      unsigned mk4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const char* sb = Qt + (qs * 16 + 4 * g + r) * STRIDE + SB;
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        const f32x2 ld2 = *(LDS_PTR(const f32x2))(sb);
+        lse4[r] = ld2[0]; del4[r] = ld2[1];
+        mk4[r] = BITS ? *(LDS_PTR(const unsigned))(sb + 4 * mdw) : 0u;
+      }
 #pragma unroll
       for (int kw = 0; kw < KW; ++kw) {
         const uint32_t key = (uint32_t)(kbase + kw * 16 + i);
+        bf16x4 dst4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pk = kvalid[kw] ? EXP2(fmaf(s[kw][qs][r], sl2, lse4[r])) : 0.f;
           float pd = pk, dpd = dp[kw][qs][r];
           if (a.thr16 != 0) {
-            // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
-            const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * QT + qs * 16 + 4 * g + r) * DROP_CA);
-            const bool keep = (key & 1u) ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16);
+            bool keep;
+            if (BITS) {
+              keep = ((mk4[r] >> mbit[kw]) & 1u) != 0u;
+            } else {
+              // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
+              const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * QT + qs * 16 + 4 * g + r) * DROP_CA);
+              keep = (key & 1u) ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16);
+            }
             pd = keep ? pk : 0.f;
             dpd = keep ? dpd : 0.f;
           }
+          const float dsv = pk * (dpd - del4[r]);
+          if (FUSED) dsum[kw] += dsv;
           pf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)pd;
-          dsf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)(pk * (dpd - del4[r]));
+          dsf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)dsv;
+          dst4[r] = (bf16_t)dsv;
         }
+        // dS^T[key][queries qs*16 + 4g .. +3]: one 8-byte store
+        if (FUSED) *(LDS_PTR(bf16x4))(dSt + (wave * KW * 16 + kw * 16 + i) * DSS + (qs * 16 + 4 * g) * 2) = dst4;
       }
     }
 #pragma unroll
@@ -671,7 +776,38 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
           dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw][kq], dk[kw][dt], 0, 0, 0);
         }
       }
-    __syncthreads();
+    __syncthreads();          // every read of this tile's Q / dO image is done; (fused) every wave's dS^T is in LDS
+    if constexpr (FUSED) {
+      // dQ[16 queries x HD/2] of this wave: query sub-tile wave>>1, output tiles (wave&1)*DT/2 .. ; contraction over all NK keys in
+      // the permuted k-order of tr_frag on BOTH operands.  Computed transposed (rows = head dim) so a lane owns 4 consecutive
+      // columns of one query row: 8-byte stores.  The dS^T buffer alternates per tile, so the next tile's stores cannot reach it.
+      const int qsub = wave >> 1, dt0 = (wave & 1) * DH;
+      f32x4 dq[DH];
+#pragma unroll
+      for (int t = 0; t < DH; ++t) dq[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < NK / 32; ++kk) {
+        const bf16x8 dsT = tr_frag(dSt, DSS, 32 * kk, qsub * 16, lane);
+#pragma unroll
+        for (int t = 0; t < DH; ++t) {
+          const bf16x8 kT = tr_frag(Ktile, STRIDE, 32 * kk, (dt0 + t) * 16, lane);
+          dq[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsT, dq[t], 0, 0, 0);
+        }
+      }
+      const int q = qt * QT + qsub * 16 + i;
+      if (q < a.Lq) {
+        bf16_t* dqp = a.dQ + ((long)b * a.Lq + q) * a.lddq + h * HD + 4 * g;
+#pragma unroll
+        for (int t = 0; t < DH; ++t) {
+          bf16x4 w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            w[r] = (bf16_t)(dq[t][r] * a.scale);
+          }
+          *(bf16x4*)(dqp + (dt0 + t) * 16) = w;
+        }
+      }
+    }
   }
   f32x4 csk[DT], csv[DT];
 #pragma unroll
@@ -698,10 +834,56 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnArgs a)
     }
   }
   if (a.cskv != nullptr) {         // kernel-uniform
-    float* row = a.cskv + (long)(b * gridDim_tiles(a.Lk, NW * KW * 16) + tile) * (2L * a.H * HD) + h * HD;
+    float* row = a.cskv + (long)(b * gridDim_tiles(a.Lk, NK) + tile) * (2L * a.H * HD) + h * HD;
     __syncthreads();
     block_colsum_store<DT, NW>(csk, (float*)lds, row, tid);
     block_colsum_store<DT, NW>(csv, (float*)lds + NW * DT * 16, row + (long)a.H * HD, tid);
+  }
+  if constexpr (FUSED) {
+    if (a.csq != nullptr) {  // column sums of the block's dQ (one partial row per (batch, head)): scale * sum_key dsum[key] * K[key][:]
+      float* red = (float*)lds + 2 * NW * DT * 16;
+      float c[KS][8];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[ks][j] = 0.f;
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        float t = dsum[kw];                       // this lane's queries only: add the other three lane groups of the key
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          {
+            const bf16x8 kf = row_frag(Ktile, STRIDE, wave * KW * 16 + kw * 16 + i, ks * 4 + g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c[ks][j] += t * (float)kf[j];
+          }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = c[ks][j];
+#pragma unroll
+          for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);      // over the 16 keys of the lane group
+          c[ks][j] = v;
+        }
+      __syncthreads();
+      if (i == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) red[wave * HD + ks * 32 + 8 * g + j] = c[ks][j];
+      }
+      __syncthreads();
+      for (int e = tid; e < HD; e += NW * 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w * HD + e];
+        a.csq[(long)b * ((long)a.H * HD) + h * HD + e] = t * a.scale;
+      }
+    }
   }
 }
 
@@ -794,18 +976,21 @@ static void fill_drop(AttnArgs& a, float p, uint64_t seed, const unsigned long l
   a.thr16 = d.thr16; a.inv_keep = d.inv_keep; a.seed = seed; a.site = site; a.b_offset = b_offset; a.seed_dev = seed_dev;
 }
 
+extern "C" long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk) { return (long)B * H * Lq * ((Lk + 63) / 64) * 8; }
+
 extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                                long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
                                int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
-                               unsigned site, int b_offset, hipStream_t st) {
+                               unsigned site, int b_offset, void* drop_mask_bits, hipStream_t st) {
   AttnArgs a = {};
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
   a.kpm = key_padding_mask; a.lse = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
   fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
+  a.mbits = (unsigned long long*)drop_mask_bits;
   if (check_common(a, head_dim)) return 1;
-  HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: unaligned O");
+  HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0 && ((uintptr_t)drop_mask_bits % 8) == 0, "attn_fwd: unaligned O / mask bits");
   hriemo_prof_begin(HP_ATTN_FWD, st);
   // two 16-row query sub-tiles per wave (K/V fragment reuse) unless the key loop is short and the 128-row tiles pad the
   // query side visibly more than 64-row tiles do (L_q = 400, L_k = 128: 512 vs 448 rows, 44.3 vs 40.5 us)
@@ -828,8 +1013,6 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   return 0;
 }
 
-// rows of the per-wave column-sum partials hriemo_attn_bwd writes for a sequence of length L on the row side of its
-// dQ (L = Lq) or dK/dV (L = Lk) kernel: B * blocks-per-(b,h), the launch geometry chosen below
 // Backward tile width for a row side of length L (queries for dQ, keys for dK/dV).  Narrow blocks (64 rows, ~160
 // VGPRs, 3 per CU) win in general; but their blocks live as long as the whole key / query loop, so a grid that fills
 // the chip 1.33 times (B*H = 512, L = 128: 1024 blocks on 768 slots) runs a second, mostly empty round.  The wide tile
@@ -853,19 +1036,43 @@ static bool bwd_wide(int L, int BH, int head_dim) {
   const double en = (double)nn / (double)(((nn + sn - 1) / sn) * sn), ew = (double)nw / (double)(((nw + sw - 1) / sw) * sw);
   return en < 0.75 && ew >= 0.9;
 }
+// Single-pass backward: one block holds all keys of a (batch, head) (16 < L_k <= 128) and produces dQ, dK and dV together
+// (5 GEMMs per tile instead of 7, Q/K/V/dO read once).  HRIEMO_ATTN_FUSED_BWD=0 restores the two-kernel path (tuning).
+static bool bwd_fused(int Lk, int head_dim) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && Lk > 16 && Lk <= 128 && head_dim >= 32;
+}
 
+// rows of the column-sum partials hriemo_attn_bwd leaves behind: dK|dV side (sequence of length Lk) ...
 extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {
+  if (bwd_fused(L, head_dim)) return B;
   if (bwd_wide(L, B * H, head_dim)) return B * ((L + 127) / 128);
   if (L > 16) return B * ((L + 63) / 64);
   return B;
 }
+// ... and dQ side (depends on both lengths: the fused kernel writes one row per (batch, head))
+extern "C" int hriemo_attn_bwd_dq_colsum_rows(int B, int H, int Lq, int Lk, int head_dim) {
+  if (bwd_fused(Lk, head_dim)) return B;
+  if (bwd_wide(Lq, B * H, head_dim)) return B * ((Lq + 127) / 128);
+  if (Lq > 16) return B * ((Lq + 63) / 64);
+  return B;
+}
+
+#define DISPATCH_HD_EVEN(hd, CALL)          \
+  switch (hd) {                             \
+    case 32: { CALL(32); } break;           \
+    case 64: { CALL(64); } break;           \
+    case 96: { CALL(96); } break;           \
+    case 128: { CALL(128); } break;         \
+  }
 
 extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
                                const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
                                long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
                                const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
                                float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
-                               float* dq_colsum_partials, float* dkv_colsum_partials, hipStream_t st) {
+                               float* dq_colsum_partials, float* dkv_colsum_partials, const void* drop_mask_bits, hipStream_t st) {
   AttnArgs a = {};
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
@@ -875,39 +1082,106 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   a.kpm = key_padding_mask; a.lse = (float*)lse; a.delta = delta; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
   fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
+  a.mbits = (unsigned long long*)drop_mask_bits;
   if (check_common(a, head_dim)) return 1;
   HRIEMO_CHECK(ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: bad leading dims");
   HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
-                   ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0, "attn_bwd: unaligned operand");
+                   ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0 && ((uintptr_t)drop_mask_bits % 8) == 0, "attn_bwd: unaligned operand");
+  const bool bits = a.thr16 != 0 && a.mbits != nullptr;
+  if (bwd_fused(Lk, head_dim)) {
+    hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
+#define CALLF(HD, KW_, BITS_) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true>), dim3(B * H), dim3(256), 0, st, a)
+    if (Lk <= 64) {
+      if (bits) {
+#define CALL(HD) CALLF(HD, 1, true)
+        DISPATCH_HD_EVEN(head_dim, CALL)
+#undef CALL
+      } else {
+#define CALL(HD) CALLF(HD, 1, false)
+        DISPATCH_HD_EVEN(head_dim, CALL)
+#undef CALL
+      }
+    } else {
+      if (bits) {
+#define CALL(HD) CALLF(HD, 2, true)
+        DISPATCH_HD_EVEN(head_dim, CALL)
+#undef CALL
+      } else {
+#define CALL(HD) CALLF(HD, 2, false)
+        DISPATCH_HD_EVEN(head_dim, CALL)
+#undef CALL
+      }
+    }
+#undef CALLF
+    HRIEMO_LAUNCH_CHECK("attn_bwd_dkv_kernel (fused dQ)");
+    hriemo_prof_end(HP_ATTN_BWD_DKV, st, 10.0 * B * H * (double)Lq * Lk * head_dim);
+    return 0;
+  }
   hriemo_prof_begin(HP_ATTN_BWD_DQ, st);
   if (bwd_wide(Lq, B * H, head_dim)) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
-    DISPATCH_HD(head_dim, CALL)
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2, true>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
 #undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 2, false>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
+#undef CALL
+    }
   } else if (Lq > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 1>), dim3(((Lq + 63) / 64) * B * H), dim3(256), 0, st, a)
-    DISPATCH_HD(head_dim, CALL)
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 1, true>), dim3(((Lq + 63) / 64) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
 #undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 4, 1, false>), dim3(((Lq + 63) / 64) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
+#undef CALL
+    }
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 1, 1>), dim3(B * H), dim3(64), 0, st, a)
-    DISPATCH_HD(head_dim, CALL)
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 1, 1, true>), dim3(B * H), dim3(64), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
 #undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, 1, 1, false>), dim3(B * H), dim3(64), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
+#undef CALL
+    }
   }
   HRIEMO_LAUNCH_CHECK("attn_bwd_dq_kernel");
   hriemo_prof_end(HP_ATTN_BWD_DQ, st, 6.0 * B * H * (double)Lq * Lk * head_dim);
   hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
   if (bwd_wide(Lk, B * H, head_dim)) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
-    DISPATCH_HD(head_dim, CALL)
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32, true, false>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
 #undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32, false, false>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
+#undef CALL
+    }
   } else if (Lk > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, DKV_QT>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
-    DISPATCH_HD(head_dim, CALL)
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, 32, true, false>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
 #undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, 32, false, false>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
+#undef CALL
+    }
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32>), dim3(B * H), dim3(64), 0, st, a)
-    DISPATCH_HD(head_dim, CALL)
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32, true, false>), dim3(B * H), dim3(64), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
 #undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32, false, false>), dim3(B * H), dim3(64), 0, st, a)
+      DISPATCH_HD(head_dim, CALL)
+#undef CALL
+    }
   }
   HRIEMO_LAUNCH_CHECK("attn_bwd_dkv_kernel");
   hriemo_prof_end(HP_ATTN_BWD_DKV, st, 8.0 * B * H * (double)Lq * Lk * head_dim);

@@ -72,19 +72,25 @@ int hriemo_gemm_mx8_force_config(int cfg);
 int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
                     const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
                     float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
-                    hriemo_stream_t stream);
+                    void* drop_mask_bits, hriemo_stream_t stream);
 int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O, long ldo,
                     const void* dO, long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
                     const unsigned char* key_padding_mask, const float* lse, float* delta, int B, int H, int Lq,
                     int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
                     unsigned site, int b_offset, float* dq_colsum_partials, float* dkv_colsum_partials,
-                    hriemo_stream_t stream);
-/* Optional by-product of hriemo_attn_bwd (either pointer may be NULL): per-block column sums of the stored dQ tiles,
- * [hriemo_attn_bwd_colsum_rows(B, H, Lq, head_dim), H*head_dim] fp32, and of the stored dK | dV tiles,
- * [hriemo_attn_bwd_colsum_rows(B, H, Lk, head_dim), 2*H*head_dim] fp32.  Summed over rows (hriemo_colreduce_batch) they are the
- * gradient of the packed in-projection bias (in_proj_bias of nn.MultiheadAttention, cross_modal_block_tacfn.py:24-40)
- * without re-reading dQ/dK/dV. */
+                    const void* drop_mask_bits, hriemo_stream_t stream);
+/* drop_mask_bits (optional, hriemo_attn_mask_bytes(B,H,Lq,Lk) bytes, 8-byte aligned): the dropout keep-mask as bits, one
+ * 64-bit word per (batch, head, query, 64-key tile), written by hriemo_attn_fwd when p_drop > 0 and read by hriemo_attn_bwd
+ * instead of replaying the hash (NULL on either side: the hash is replayed; both give the same mask).
+ * For 16 < Lk <= 128 hriemo_attn_bwd is ONE kernel (dQ, dK, dV together; `delta` is then not written). */
+long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk);
+/* Optional by-product of hriemo_attn_bwd (either pointer may be NULL): per-block column sums of the dQ tiles,
+ * [hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, head_dim), H*head_dim] fp32, and of the dK | dV tiles,
+ * [hriemo_attn_bwd_colsum_rows(B, H, Lk, head_dim), 2*H*head_dim] fp32 (values before their bf16 rounding).  Summed over rows
+ * (hriemo_colreduce_batch) they are the gradient of the packed in-projection bias (in_proj_bias of nn.MultiheadAttention,
+ * cross_modal_block_tacfn.py:24-40) without re-reading dQ/dK/dV. */
 int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim);
+int hriemo_attn_bwd_dq_colsum_rows(int B, int H, int Lq, int Lk, int head_dim);
 /* head-averaged attention probabilities [B,Lq,Lk] fp32 (need_weights=True; return_attention path,
  * cross_modal_block_tacfn.py:70-125, emotion_decoder.py:48-64) */
 int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,

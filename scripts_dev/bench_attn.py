@@ -14,13 +14,13 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / reps * 1e3
-for name, Lq, Lk in [("self_a", 400, 400), ("a2t (q=audio,k=text)", 400, 128), ("t2a (q=text,k=audio)", 128, 400), ("self_t", 128, 128)]:
+for name, Lq, Lk in [("self_a", 400, 400), ("a2t (q=audio,k=text)", 400, 128), ("t2a (q=text,k=audio)", 128, 400), ("self_t", 128, 128), ("decoder cross", 6, 128)]:
     for p in (0.0, 0.1):
         q = torch.randn(B * Lq, d, device="cuda").bfloat16(); k = torch.randn(B * Lk, d, device="cuda").bfloat16(); v = torch.randn(B * Lk, d, device="cuda").bfloat16()
-        o, lse = _ops.attn_fwd(q, k, v, B, H, Lq, Lk, hd, None, p, 1234, 5, 0)
+        o, lse, mb = _ops.attn_fwd(q, k, v, B, H, Lq, Lk, hd, None, p, 1234, 5, 0, want_bits=True)
         do = torch.randn_like(o); dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
-        tf = timeit(lambda: _ops.attn_fwd(q, k, v, B, H, Lq, Lk, hd, None, p, 1234, 5, 0))
-        tb = timeit(lambda: _ops.attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, None, p, 1234, 5, 0))
+        tf = timeit(lambda: _ops.attn_fwd(q, k, v, B, H, Lq, Lk, hd, None, p, 1234, 5, 0, want_bits=True))
+        tb = timeit(lambda: _ops.attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, None, p, 1234, 5, 0, mask_bits=mb))
         fl = 4.0 * B * H * Lq * Lk * hd
         ai = Lq * Lk / (Lq + Lk)
         roof = min(2500.0, ai * 8.0)            # TFLOP/s

@@ -137,6 +137,11 @@ ATTN_CASES = [  # B, H, Lq, Lk, hd, masked, p
     (1, 2, 200, 200, 128, False, 0.0),
     (1, 4, 50, 1000, 32, True, 0.0),
     (64, 8, 128, 70, 96, True, 0.1),      # B*H = 512 at L <= 128: the backward picks its 128-row tiles (one round of blocks)
+    (2, 8, 6, 128, 96, True, 0.1),        # decoder cross-attention: N_e = 6 queries over the fused memory (single-pass backward)
+    (2, 4, 100, 128, 128, True, 0.1),     # head_dim 128 (cfg 5), all 128 keys in one block
+    (3, 4, 70, 40, 64, True, 0.1),        # L_k <= 64: one 16-key sub-tile per wave
+    (2, 2, 33, 17, 32, False, 0.2),
+    (2, 8, 400, 129, 96, True, 0.1),      # one key past the single-pass limit: two-kernel path with the bit-word mask
 ]
 
 
@@ -165,10 +170,21 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
 
     qd, kvd, dod = qb.cuda(), kvb.cuda(), dob.cuda()
     kpm_d = kpm.cuda().view(torch.uint8) if kpm is not None else None
-    o, lse = ops.attn_fwd(qd, kvd[:, :d], kvd[:, d:], B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff)
+    o, lse, mbits = ops.attn_fwd(qd, kvd[:, :d], kvd[:, d:], B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff, want_bits=True)
     tol = 2e-2     # bf16 P and bf16 O: ~2^-8 relative on O(1) values
     assert (o.float().cpu() - o_ref2.detach()).abs().max() <= tol * max(1.0, o_ref2.abs().max().item())
     assert (lse.cpu() - lse_ref.detach()).abs().max() <= 2e-3 * max(1.0, lse_ref.abs().max().item())
+    if p > 0:
+        # the keep-mask bit words the forward leaves for the backward: bit 16*g + 4*n + r of word (b, h, q, tile)
+        # <-> key 64*tile + 16*n + 4*g + r, equal to the host replica of the hash
+        nkt = (Lk + 63) // 64
+        w = mbits.view(B, H, Lq, nkt).cpu().numpy().astype(np.uint64)
+        key = np.arange(Lk)
+        bitpos = ((key % 16) // 4) * 16 + ((key % 64) // 16) * 4 + key % 4
+        got_keep = ((w[..., key // 64] >> bitpos.astype(np.uint64)) & np.uint64(1)).astype(bool)
+        assert np.array_equal(got_keep, keep.numpy().astype(bool))
+    else:
+        assert mbits is None
 
     probs = ops.attn_probs(qd, kvd[:, :d], B, H, Lq, Lk, hd, kpm_d, lse, p, seed, site, boff)
     assert (probs.cpu() - pd_ref.detach().mean(1)).abs().max() <= 5e-3
@@ -178,18 +194,23 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
     dq = torch.empty_like(qd)
     dkv = torch.empty_like(kvd)
     ops.attn_bwd(qd, kvd[:, :d], kvd[:, d:], o, dod, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm_d, p, seed,
-                 site, boff)
+                 site, boff, mask_bits=mbits)
     dq_ref = q.grad.transpose(1, 2).reshape(B * Lq, d)
     dk_ref = k.grad.transpose(1, 2).reshape(B * Lk, d)
     dv_ref = v.grad.transpose(1, 2).reshape(B * Lk, d)
     for name, got, ref in (("dq", dq, dq_ref), ("dk", dkv[:, :d], dk_ref), ("dv", dkv[:, d:], dv_ref)):
         err = (got.float().cpu() - ref).abs().max().item()
         assert err <= 3e-2 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+    if p > 0:       # mask from the bit words == mask replayed from the hash: same kernels, bit-identical gradients
+        dq_h, dkv_h = torch.empty_like(qd), torch.empty_like(kvd)
+        ops.attn_bwd(qd, kvd[:, :d], kvd[:, d:], o, dod, dq_h, dkv_h[:, :d], dkv_h[:, d:], lse, B, H, Lq, Lk, hd, kpm_d, p, seed,
+                     site, boff, mask_bits=None)
+        assert torch.equal(dq_h, dq) and torch.equal(dkv_h, dkv)
 
-    # by-product: per-block column sums of the stored dQ and dK|dV (in-projection bias gradient) through the C-ABI
+    # by-product: per-block column sums of dQ and dK|dV (in-projection bias gradient) through the C-ABI
     from hri_emo_amd import _lib
     L_ = _lib.lib()
-    rq, rk = L_.hriemo_attn_bwd_colsum_rows(B, H, Lq, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
+    rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
     pq = torch.full((rq, d), float("nan"), device="cuda")
     pkv = torch.full((rk, 2 * d), float("nan"), device="cuda")
     dq2, dkv2 = torch.empty_like(qd), torch.empty_like(kvd)
@@ -200,7 +221,7 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
               dkv2[:, :d].data_ptr(), dkv2.stride(0), dkv2[:, d:].data_ptr(), dkv2.stride(0),
               kpm_d.data_ptr() if kpm_d is not None else None, lse.data_ptr(), delta.data_ptr(), B, H, Lq, Lk, hd, float(p),
               seed, ops.seed_word(qd.device).data_ptr(), site, boff, pq.data_ptr(), pkv.data_ptr(),
-              torch.cuda.current_stream().cuda_stream)
+              mbits.data_ptr() if mbits is not None else None, torch.cuda.current_stream().cuda_stream)
     assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv)
     # the partials are sums of the fp32 values BEFORE their bf16 rounding: compared with the column sums of the fp32 reference
     # gradients (tolerance: the bf16 P / dS operands of the kernels, summed over B*L rows), and they must be at least as close to
