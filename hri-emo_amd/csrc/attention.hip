@@ -36,6 +36,7 @@ struct AttnArgs {
   int B, H, Lq, Lk;
   float scale;
   uint32_t thr16; float inv_keep; uint64_t seed; uint32_t site; int b_offset;
+  float l2ik, keepfrac;          // log2(1/(1-p)) and (1-p) (0 and 1 without dropout): scalars for the backward kernels
   const unsigned long long* seed_dev;
   // Dropout keep-mask as BITS, written once by the forward and read by both backward kernels instead of re-hashing
   // (3.3 MB per cross-attention site at cfg 2 against ~7 VALU operations per element and kernel).  One 64-bit word per
@@ -553,7 +554,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 //          and stores it.  delta = rowsum(dO * O) is computed here as well (8 lanes per query row).
 // Per query row the Q image's 32 pad bytes carry the row's sideband: {lse', delta', keep-mask dwords [tile][half]}.
 template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED>
-__global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
+// two waves per SIMD are only requested where the kernel fits 256 registers WITHOUT spilling: co-resident blocks of the spilling
+// builds gave wrong dS elements on hardware (scripts_dev/dbg_attn.py; a single block per CU of the same code was exact)
+__global__ __launch_bounds__(NW * 64, (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED))) ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32, "query tile");
@@ -567,7 +570,10 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
   constexpr int IMG = 2 * QT * STRIDE;               // Q image + dO image
   constexpr int DSS = QT * 2 + 32;                   // row stride of the dS^T tile ([key][QT queries] bf16)
   constexpr int KT_BYTES = FUSED ? NK * STRIDE : 0, DST_BYTES = FUSED ? NK * DSS : 0;
-  __shared__ __attribute__((aligned(16))) char lds[2 * IMG + KT_BYTES + 2 * DST_BYTES];
+#ifndef HRIEMO_DBG_LDS_PAD
+#define HRIEMO_DBG_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) char lds[2 * IMG + KT_BYTES + 2 * DST_BYTES + HRIEMO_DBG_LDS_PAD];
   char* const Ktile = lds + 2 * IMG;
   char* const dSt0 = Ktile + KT_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
@@ -604,16 +610,19 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
   const float sl2 = a.scale * LOG2E;
   const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
   uint32_t hkb[KW];                     // hash base of this lane's key: key32 + (key>>1)*CB  (a-term added per query)
-  int mbit[KW];                         // BITS: bit of this lane's key inside its mask dword, and which dword of the sideband
 #pragma unroll
-  for (int kw = 0; kw < KW; ++kw) {
-    hkb[kw] = drop_base(key32, 0u, (uint32_t)((kbase + kw * 16 + i) >> 1));
-    const int kloc = (kbase + kw * 16) & 63;        // 16-key subtile n = kloc / 16 of its 64-key tile
-    mbit[kw] = ((i >> 2) * 16 + (kloc >> 4) * 4 + (i & 3)) & 31;
-  }
-  // sideband dword of this lane: tile (kbase relative to the block's first key) and half (i >= 8); the same for every kw of
-  // a wave when KW <= 2 (a wave's 32 keys never straddle a 64-key tile)
-  const int mdw = 2 + (((kbase - tile * NK) >> 6) * 2 + (i >> 3));
+  for (int kw = 0; kw < KW; ++kw) hkb[kw] = drop_base(key32, 0u, (uint32_t)((kbase + kw * 16 + i) >> 1));
+  // BITS: this lane's key (sub-tile 0) sits at bit mbit0 of sideband dword mdw: tile = (kbase relative to the block's first key)
+  // / 64, half = i >= 8; the same dword for every sub-tile of a wave when KW <= 2 (a wave's 32 keys never straddle a 64-key
+  // tile).  Both are rebuilt from the lane id where they are used (a few VALU operations per tile) instead of living in two
+  // registers across the loop: this kernel runs at the 256-register limit of two waves per SIMD.
+  auto mask_pos = [&](int& mbit0, int& mdw) {
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));        // opaque: keeps the rebuild inside the loop
+    const int i2 = l2 & 15;
+    mbit0 = ((i2 >> 2) * 16 + ((kbase & 63) >> 4) * 4 + (i2 & 3)) & 31;
+    mdw = 2 + (((kbase - tile * NK) >> 6) * 2 + (i2 >> 3));
+  };
   const int nkt_all = (a.Lk + 63) >> 6, kt0 = (tile * NK) >> 6;
   const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
   const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
   const long lbase = ((long)b * a.H + h) * a.Lq;
   const int nqt = (a.Lq + QT - 1) / QT;
 
-  const float l2ik = a.thr16 != 0 ? log2f(a.inv_keep) : 0.f, keepfrac = a.thr16 != 0 ? 1.f / a.inv_keep : 1.f;
+  const float l2ik = a.l2ik, keepfrac = a.keepfrac;
   TileRegs<HD, QT, NT> qr, dor;
   // sideband of query row `tid` of the tile in flight (threads tid < QT): lse', delta' (not fused), mask words
   float lse_r = 0.f, del_r = 0.f;
@@ -646,9 +655,11 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
     part += __shfl_xor(part, 4);
     return part * keepfrac;
   };
-  auto fetch = [&](int qt) {
+  auto fetch = [&](int qt) {          // Q / dO rows of tile qt: global -> registers
     tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, qt * QT, a.Lq, tid);
     tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, qt * QT, a.Lq, tid);
+  };
+  auto fetch_side = [&](int qt) {     // sideband of tile qt: global -> registers (threads tid < QT; fused: delta by all threads)
     if (tid < QT) {
       const int q = qt * QT + tid;
       lse_r = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
@@ -659,11 +670,10 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
           mw_r[t] = (q < a.Lq && kt0 + t < nkt_all) ? a.mbits[(lbase + q) * nkt_all + kt0 + t] : 0ull;
       }
     }
+    if (FUSED) del_part = delta_of(qt);
   };
-  auto commit = [&](int buf) {
+  auto commit_side = [&](int buf) {   // sideband registers -> the pad bytes of image `buf` (which no wave is reading any more)
     char* base = lds + buf * IMG;
-    tile_commit<HD, QT, NT>(qr, base, tid);
-    tile_commit<HD, QT, NT>(dor, base + QT * STRIDE, tid);
     if (tid < QT) {
       char* sb = base + tid * STRIDE + SB;
       *(LDS_PTR(float))(sb) = lse_r;
@@ -678,10 +688,19 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
     }
     if (FUSED && (tid & 7) == 0) *(LDS_PTR(float))(base + (tid >> 3) * STRIDE + SB + 4) = del_part;
   };
+  auto commit = [&](int buf) {        // Q / dO registers -> image `buf`
+    char* base = lds + buf * IMG;
+    tile_commit<HD, QT, NT>(qr, base, tid);
+    tile_commit<HD, QT, NT>(dor, base + QT * STRIDE, tid);
+  };
+  // Pipeline of the query tiles: tile t is FETCHED (global -> registers) right after the barrier that closes iteration t-2,
+  // COMMITTED (registers -> LDS image t & 1) right after the S / dP MFMAs of iteration t-1, and consumed in iteration t.  The
+  // staging registers are therefore dead during the register-hungry part of an iteration (softmax, dS^T, dV / dK).
   fetch(0);
-  if (FUSED) del_part = delta_of(0);
+  fetch_side(0);
   commit(0);
-  if (nqt > 1) { fetch(1); if (FUSED) del_part = delta_of(1); }
+  commit_side(0);
+  if (nqt > 1) { fetch(1); fetch_side(1); commit_side(1); }
   __syncthreads();
   // fused: colsum(dQ) = (sum over queries of dS) . K -- one running sum per key instead of accumulators over the dQ slices
   float dsum[KW];
@@ -690,21 +709,17 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
   for (int qt = 0; qt < nqt; ++qt) {
     const char* Qt = lds + (qt & 1) * IMG;
     const char* dOt = Qt + QT * STRIDE;
-    if (qt + 1 < nqt) {
-      commit((qt + 1) & 1);                       // image last read in iteration qt-1, released by its closing barrier
-      if (qt + 2 < nqt) { fetch(qt + 2); if (FUSED) del_part = delta_of(qt + 2); }
-    }
-
-    f32x4 s[KW][NQS], dp[KW][NQS];
+    bf16x8 pf[KW][NKQ], dsf[KW][NKQ];
+    char* const dSt = dSt0 + (qt & 1) * DST_BYTES;
 #pragma unroll
-    for (int kw = 0; kw < KW; ++kw)
+    for (int qs = 0; qs < NQS; ++qs) {
+      // S and dP of the 16 query rows qs*16 .. +15 against this wave's keys; the next sub-tile's MFMAs overlap this one's softmax
+      f32x4 s[KW], dp[KW];
 #pragma unroll
-      for (int qs = 0; qs < NQS; ++qs) {
-        s[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kw = 0; kw < KW; ++kw) {
+        s[kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-    for (int qs = 0; qs < NQS; ++qs)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 qfr = row_frag(Qt, STRIDE, qs * 16 + i, ks * 4 + g);
@@ -714,18 +729,17 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
           bf16x8 kf;
           if constexpr (FUSED) kf = row_frag(Ktile, STRIDE, wave * KW * 16 + kw * 16 + i, ks * 4 + g);
           else kf = kreg[kw][ks];
-          s[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf, s[kw][qs], 0, 0, 0);
-          dp[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vreg[kw][ks], dp[kw][qs], 0, 0, 0);
+          s[kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf, s[kw], 0, 0, 0);
+          dp[kw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vreg[kw][ks], dp[kw], 0, 0, 0);
         }
       }
-    bf16x8 pf[KW][NKQ], dsf[KW][NKQ];
-    char* const dSt = dSt0 + (qt & 1) * DST_BYTES;
-#pragma unroll
-    for (int qs = 0; qs < NQS; ++qs) {
+      if (qs == NQS - 1 && qt + 1 < nqt) commit((qt + 1) & 1);      // image last read in iteration qt-1, released by its barrier
       // sideband of query rows qs*16 + 4g + r: lse' = log2(1/(1-p_drop)) - lse*log2e, delta' = delta*(1-p_drop): pk = p/(1-p_drop)
       // straight from the exponent, P~ = keep ? pk : 0, dS = pk * (keep ? dP : 0  -  delta')
       float lse4[4], del4[4];
       unsigned mk4[4];
+      int mbit0 = 0, mdw = 0;
+      if (BITS) mask_pos(mbit0, mdw);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const char* sb = Qt + (qs * 16 + 4 * g + r) * STRIDE + SB;
@@ -737,15 +751,14 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
 #pragma unroll
       for (int kw = 0; kw < KW; ++kw) {
         const uint32_t key = (uint32_t)(kbase + kw * 16 + i);
-        bf16x4 dst4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pk = kvalid[kw] ? EXP2(fmaf(s[kw][qs][r], sl2, lse4[r])) : 0.f;
-          float pd = pk, dpd = dp[kw][qs][r];
-          if (a.thr16 != 0) {
+          const float pk = kvalid[kw] ? EXP2(fmaf(s[kw][r], sl2, lse4[r])) : 0.f;
+          float pd = pk, dpd = dp[kw][r];
+          if (BITS || a.thr16 != 0) {               // BITS kernels are only launched with dropout on
             bool keep;
             if (BITS) {
-              keep = ((mk4[r] >> mbit[kw]) & 1u) != 0u;
+              keep = ((mk4[r] >> (mbit0 + 4 * kw)) & 1u) != 0u;     // the wave's sub-tiles are neighbours: n -> n + 1 is 4 bits up
             } else {
               // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
               const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * QT + qs * 16 + 4 * g + r) * DROP_CA);
@@ -758,10 +771,13 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
           if (FUSED) dsum[kw] += dsv;
           pf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)pd;
           dsf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)dsv;
-          dst4[r] = (bf16_t)dsv;
         }
-        // dS^T[key][queries qs*16 + 4g .. +3]: one 8-byte store
-        if (FUSED) *(LDS_PTR(bf16x4))(dSt + (wave * KW * 16 + kw * 16 + i) * DSS + (qs * 16 + 4 * g) * 2) = dst4;
+        // dS^T[key][queries qs*16 + 4g .. +3]: one 8-byte store, straight from the half of the operand register just filled
+        if (FUSED) {
+          const bf16x8 f = dsf[kw][qs >> 1];
+          const bf16x4 h4 = (qs & 1) ? (bf16x4){f[4], f[5], f[6], f[7]} : (bf16x4){f[0], f[1], f[2], f[3]};
+          *(LDS_PTR(bf16x4))(dSt + (wave * KW * 16 + kw * 16 + i) * DSS + (qs * 16 + 4 * g) * 2) = h4;
+        }
       }
     }
 #pragma unroll
@@ -775,8 +791,12 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
           dv[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf[kw][kq], dv[kw][dt], 0, 0, 0);
           dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw][kq], dk[kw][dt], 0, 0, 0);
         }
+        if (FUSED && KW == 2 && (dt & 1)) __builtin_amdgcn_sched_barrier(0);      // at most two tiles' fragments in flight (registers)
       }
     __syncthreads();          // every read of this tile's Q / dO image is done; (fused) every wave's dS^T is in LDS
+    // image qt & 1 is released: start tile qt+2 (its Q / dO rows stay in registers until the S / dP MFMAs of the next iteration
+    // are issued; its sideband goes to the pad bytes of the released image behind the dQ phase, off the register-hungry part)
+    if (qt + 2 < nqt) { fetch(qt + 2); fetch_side(qt + 2); }
     if constexpr (FUSED) {
       // dQ[16 queries x HD/2] of this wave: query sub-tile wave>>1, output tiles (wave&1)*DT/2 .. ; contraction over all NK keys in
       // the permuted k-order of tr_frag on BOTH operands.  Computed transposed (rows = head dim) so a lane owns 4 consecutive
@@ -808,16 +828,20 @@ __global__ __launch_bounds__(NW * 64, (FUSED && HD <= 96) ? 2 : 1) void attn_bwd
         }
       }
     }
+    if (qt + 2 < nqt) commit_side(qt & 1);
   }
   f32x4 csk[DT], csv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { csk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; csv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));       // opaque: the epilogue's lane-derived addresses are rebuilt here, not carried through the loop
+  const int i_e = tid_e & 15, g_e = (tid_e >> 4) & 3, kbase_e = tile * NK + (tid_e >> 6) * KW * 16;
 #pragma unroll
   for (int kw = 0; kw < KW; ++kw) {
-    const int key = kbase + kw * 16 + i;
+    const int key = kbase_e + kw * 16 + i_e;
     if (key >= a.Lk) continue;
-    bf16_t* dkp = a.dK + ((long)b * a.Lk + key) * a.lddk + h * HD + 4 * g;
-    bf16_t* dvp = a.dV + ((long)b * a.Lk + key) * a.lddv + h * HD + 4 * g;
+    bf16_t* dkp = a.dK + ((long)b * a.Lk + key) * a.lddk + h * HD + 4 * g_e;
+    bf16_t* dvp = a.dV + ((long)b * a.Lk + key) * a.lddv + h * HD + 4 * g_e;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       bf16x4 wk, wv;
@@ -974,6 +998,8 @@ static int check_common(const AttnArgs& a, int hd) {
 static void fill_drop(AttnArgs& a, float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, int b_offset) {
   DropCfg d = make_drop(p, seed, site);
   a.thr16 = d.thr16; a.inv_keep = d.inv_keep; a.seed = seed; a.site = site; a.b_offset = b_offset; a.seed_dev = seed_dev;
+  a.l2ik = d.thr16 != 0 ? log2f(d.inv_keep) : 0.f;
+  a.keepfrac = d.thr16 != 0 ? 1.f / d.inv_keep : 1.f;
 }
 
 extern "C" long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk) { return (long)B * H * Lq * ((Lk + 63) / 64) * 8; }

@@ -1,0 +1,45 @@
+import os, sys, math, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import hri_emo_amd
+from hri_emo_amd import _ops as ops
+import hashrng
+def run(B, H, Lq, Lk, hd, masked, p, use_bits=True):
+    g = torch.Generator().manual_seed(100 + Lq + Lk)
+    d = H * hd
+    qb = (torch.randn(B * Lq, d, generator=g) * 1.5).bfloat16()
+    kvb = torch.randn(B * Lk, 2 * d, generator=g).bfloat16()
+    dob = torch.randn(B * Lq, d, generator=g).bfloat16()
+    kpm = None
+    if masked:
+        lens = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+        kpm = torch.arange(Lk)[None, :] >= lens[:, None]
+    seed, site, boff = 1234567890123, 40, 5
+    keep = torch.from_numpy(hashrng.attn_mask(seed, site, B, H, Lq, Lk, p, boff)).float() if p > 0 else None
+    q = qb.float().view(B, Lq, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    k = kvb[:, :d].float().contiguous().view(B, Lk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    v = kvb[:, d:].float().contiguous().view(B, Lk, H, hd).transpose(1, 2).detach().requires_grad_(True)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+    if kpm is not None: s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    pr = torch.softmax(s, -1)
+    pd = pr if keep is None else pr * keep * hashrng.inv_keep(p)
+    o_ref = (pd @ v).transpose(1, 2).reshape(B * Lq, d)
+    o_ref.backward(dob.float())
+    qd, kvd, dod = qb.cuda(), kvb.cuda(), dob.cuda()
+    kpm_d = kpm.cuda().view(torch.uint8) if kpm is not None else None
+    o, lse, mb = ops.attn_fwd(qd, kvd[:, :d], kvd[:, d:], B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff, want_bits=True)
+    dq = torch.empty_like(qd); dkv = torch.empty_like(kvd)
+    ops.attn_bwd(qd, kvd[:, :d], kvd[:, d:], o, dod, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff, mask_bits=mb if use_bits else None)
+    refs = dict(dq=q.grad.transpose(1, 2).reshape(B, Lq, H, hd), dk=k.grad.transpose(1, 2).reshape(B, Lk, H, hd), dv=v.grad.transpose(1, 2).reshape(B, Lk, H, hd))
+    gots = dict(dq=dq.float().cpu().view(B, Lq, H, hd), dk=dkv[:, :d].float().cpu().view(B, Lk, H, hd), dv=dkv[:, d:].float().cpu().view(B, Lk, H, hd))
+    print(f"case B{B} H{H} Lq{Lq} Lk{Lk} hd{hd} masked={masked} p={p} bits={use_bits} fused_env={os.environ.get('HRIEMO_ATTN_FUSED_BWD')}")
+    for n in refs:
+        e = (gots[n] - refs[n]).abs()
+        bad = (e > 3e-2 * max(1.0, refs[n].abs().max().item()))
+        print(f"  {n}: max err {e.max():.3f} (ref max {refs[n].abs().max():.2f}) bad elements {int(bad.sum())} / {bad.numel()}")
+        if bad.any():
+            idx = bad.nonzero()
+            print("    bad (b,row,h):", sorted(set((int(x[0]), int(x[1]), int(x[2])) for x in idx))[:30])
+            if kpm is not None: print("    lens of bad b:", [int(lens[b]) for b in sorted(set(idx[:, 0].tolist()))[:20]])
+for args in [(64, 8, 400, 128, 96, False, 0.1, True), (64, 8, 128, 128, 96, False, 0.1, True)]:
+    run(*args)
