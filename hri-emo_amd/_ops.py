@@ -449,6 +449,7 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
             red.add(pq, d, rq, d, 1, [bias_grad[0]], deferred, schedule=False)
             red.add(pkv, 2 * d, rk, 2 * d, 1, [bias_grad[1]], deferred, schedule=False)
             red.flush()
+    attn_bwd.last_delta = delta          # scratch of the last call (diagnostics: scripts_dev/dbg_attn.py)
     return fold
 
 

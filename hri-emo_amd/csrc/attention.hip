@@ -136,8 +136,7 @@ __device__ __forceinline__ void tile_commit(const TileRegs<HD, NR, NT>& t, char*
 // re-fetches that head's K/V (or Q/dO) through the fabric: 230-390 MB per launch measured (profiles/
 // r01_hbm_traffic.json).  Here blocks l, l+8, l+16, ... (one XCD) walk the tiles of the SAME (batch, head)
 // before moving on, so its operands are fetched once per XCD.  Placement only affects speed.
-__device__ __forceinline__ void tile_and_head(int ntiles, int nbh, int& tile, int& bh) {
-  const int l = blockIdx.x;
+__device__ __forceinline__ void tile_and_head(int ntiles, int nbh, int& tile, int& bh, int l = blockIdx.x) {
   const int full = (nbh >> 3) << 3;                 // heads covered by complete groups of 8
   const int lim = full * ntiles;
   if (l < lim) {
@@ -553,10 +552,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 //          [16 query x HD/2] slice of dQ = dS.K over all NK keys (K^T fragments by transposed reads of the block's K tile)
 //          and stores it.  delta = rowsum(dO * O) is computed here as well (8 lanes per query row).
 // Per query row the Q image's 32 pad bytes carry the row's sideband: {lse', delta', keep-mask dwords [tile][half]}.
-template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED>
+template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED, bool PAIR = false>
 // two waves per SIMD are only requested where the kernel fits 256 registers WITHOUT spilling: co-resident blocks of the spilling
 // builds gave wrong dS elements on hardware (scripts_dev/dbg_attn.py; a single block per CU of the same code was exact)
-__global__ __launch_bounds__(NW * 64, (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED))) ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED)))) ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32, "query tile");
@@ -570,15 +569,19 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 && NW == 4 && (KW == 1 || (BITS 
   constexpr int IMG = 2 * QT * STRIDE;               // Q image + dO image
   constexpr int DSS = QT * 2 + 32;                   // row stride of the dS^T tile ([key][QT queries] bf16)
   constexpr int KT_BYTES = FUSED ? NK * STRIDE : 0, DST_BYTES = FUSED ? NK * DSS : 0;
-#ifndef HRIEMO_DBG_LDS_PAD
-#define HRIEMO_DBG_LDS_PAD 0
-#endif
-  __shared__ __attribute__((aligned(16))) char lds[2 * IMG + KT_BYTES + 2 * DST_BYTES + HRIEMO_DBG_LDS_PAD];
+  constexpr int LDS_ONE = 2 * IMG + KT_BYTES + 2 * DST_BYTES;
+  // PAIR: one workgroup of 2*NW waves = two independent (batch, head) problems, each with its own NW waves and its own LDS half;
+  // they only share the barriers (same trip counts).  The fused kernel at 128 keys needs half the CU's LDS and a full register
+  // budget per problem: as TWO workgroups per CU it returned wrong dS elements on hardware (one workgroup per CU was exact, with
+  // or without spills, exact LDS fit or not -- scripts_dev/dbg_attn.py), as one paired workgroup it keeps two waves per SIMD.
+  __shared__ __attribute__((aligned(16))) char lds_all[LDS_ONE * (PAIR ? 2 : 1)];
+  const int sub = PAIR ? (int)(threadIdx.x / (NW * 64)) : 0;
+  char* const lds = lds_all + sub * LDS_ONE;
   char* const Ktile = lds + 2 * IMG;
   char* const dSt0 = Ktile + KT_BYTES;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int tid = PAIR ? (int)(threadIdx.x % (NW * 64)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
-  tile_and_head((a.Lk + NK - 1) / NK, a.B * a.H, tile, bh);
+  tile_and_head((a.Lk + NK - 1) / NK, a.B * a.H, tile, bh, PAIR ? (int)blockIdx.x * 2 + sub : (int)blockIdx.x);
   const int b = bh / a.H, h = bh - b * a.H;
   const int kbase = tile * NK + wave * KW * 16;
 
@@ -659,7 +662,9 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 && NW == 4 && (KW == 1 || (BITS 
     tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, qt * QT, a.Lq, tid);
     tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, qt * QT, a.Lq, tid);
   };
+  int side_q = 0;                     // first query row of the tile whose sideband is in flight
   auto fetch_side = [&](int qt) {     // sideband of tile qt: global -> registers (threads tid < QT; fused: delta by all threads)
+    side_q = qt * QT;
     if (tid < QT) {
       const int q = qt * QT + tid;
       lse_r = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
@@ -686,7 +691,10 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 && NW == 4 && (KW == 1 || (BITS 
         }
       }
     }
-    if (FUSED && (tid & 7) == 0) *(LDS_PTR(float))(base + (tid >> 3) * STRIDE + SB + 4) = del_part;
+    if (FUSED && (tid & 7) == 0) {
+      *(LDS_PTR(float))(base + (tid >> 3) * STRIDE + SB + 4) = del_part;
+      if (a.delta != nullptr && side_q + (tid >> 3) < a.Lq) a.delta[lbase + side_q + (tid >> 3)] = del_part;     // (1 - p) * rowsum(dO * O)
+    }
   };
   auto commit = [&](int buf) {        // Q / dO registers -> image `buf`
     char* base = lds + buf * IMG;
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 && NW == 4 && (KW == 1 || (BITS 
   f32x4 csk[DT], csv[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { csk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; csv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  int tid_e = threadIdx.x;
+  int tid_e = PAIR ? (int)(threadIdx.x % (NW * 64)) : (int)threadIdx.x;
   asm volatile("" : "+v"(tid_e));       // opaque: the epilogue's lane-derived addresses are rebuilt here, not carried through the loop
   const int i_e = tid_e & 15, g_e = (tid_e >> 4) & 3, kbase_e = tile * NK + (tid_e >> 6) * KW * 16;
 #pragma unroll
@@ -1063,23 +1071,28 @@ static bool bwd_wide(int L, int BH, int head_dim) {
   return en < 0.75 && ew >= 0.9;
 }
 // Single-pass backward: one block holds all keys of a (batch, head) (16 < L_k <= 128) and produces dQ, dK and dV together
-// (5 GEMMs per tile instead of 7, Q/K/V/dO read once).  HRIEMO_ATTN_FUSED_BWD=0 restores the two-kernel path (tuning).
-static bool bwd_fused(int Lk, int head_dim) {
+// (5 GEMMs per tile instead of 7, Q/K/V/dO read once): a2t backward 63 us instead of 105 at cfg 2.
+// OFF by default (HRIEMO_ATTN_FUSED_BWD=1 turns it on): with the bit-word mask and two waves per SIMD it returned a few
+// wrong dS elements per launch on hardware (P~, delta and the masks themselves exact; the hash-mask build and every build at
+// one wave per SIMD exact; two workgroups per CU or one paired workgroup alike; with or without spills; cause not found --
+// scripts_dev/dbg_attn.py).  A kernel that is only right when nothing shares its SIMD does not ship.
+static bool bwd_fused(int Lk, int head_dim, int BH) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on && Lk > 16 && Lk <= 128 && head_dim >= 32;
+  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '1') ? 1 : 0; }
+  // (an odd number of (batch, head) problems cannot be paired: two-kernel path)
+  return on && Lk > 16 && Lk <= 128 && head_dim >= 32 && (BH % 2 == 0 || (head_dim == 128 && Lk > 64));
 }
 
 // rows of the column-sum partials hriemo_attn_bwd leaves behind: dK|dV side (sequence of length Lk) ...
 extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {
-  if (bwd_fused(L, head_dim)) return B;
+  if (bwd_fused(L, head_dim, B * H)) return B;
   if (bwd_wide(L, B * H, head_dim)) return B * ((L + 127) / 128);
   if (L > 16) return B * ((L + 63) / 64);
   return B;
 }
 // ... and dQ side (depends on both lengths: the fused kernel writes one row per (batch, head))
 extern "C" int hriemo_attn_bwd_dq_colsum_rows(int B, int H, int Lq, int Lk, int head_dim) {
-  if (bwd_fused(Lk, head_dim)) return B;
+  if (bwd_fused(Lk, head_dim, B * H)) return B;
   if (bwd_wide(Lq, B * H, head_dim)) return B * ((Lq + 127) / 128);
   if (Lq > 16) return B * ((Lq + 63) / 64);
   return B;
@@ -1114,9 +1127,20 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
                    ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0 && ((uintptr_t)drop_mask_bits % 8) == 0, "attn_bwd: unaligned operand");
   const bool bits = a.thr16 != 0 && a.mbits != nullptr;
-  if (bwd_fused(Lk, head_dim)) {
+  if (bwd_fused(Lk, head_dim, B * H)) {
     hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
-#define CALLF(HD, KW_, BITS_) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true>), dim3(B * H), dim3(256), 0, st, a)
+    // PAIR (two (batch, head) problems per workgroup, one workgroup per CU) whenever two problems fit the CU's LDS; otherwise a
+    // problem needs more than half the LDS and is alone on its CU anyway
+#define CALLF(HD, KW_, BITS_)                                                                                                    \
+  {                                                                                                                              \
+    constexpr int lds_one__ = 4 * 32 * AttnGeom<HD>::STRIDE + (4 * KW_ * 16) * AttnGeom<HD>::STRIDE + 2 * (4 * KW_ * 16) * 96;     \
+    if constexpr (2 * lds_one__ <= 160 * 1024) {                                                                                 \
+      if ((B * H) % 2 == 0) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true>), dim3(B * H / 2), dim3(512), 0, st, a); \
+      else { hriemo_set_error("attn_bwd: internal: odd (batch, head) count reached the paired kernel"); return 1; }            \
+    } else {                                                                                                                     \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);             \
+    }                                                                                                                            \
+  }
     if (Lk <= 64) {
       if (bits) {
 #define CALL(HD) CALLF(HD, 1, true)

@@ -29,9 +29,21 @@ def run(B, H, Lq, Lk, hd, masked, p, use_bits=True):
     kpm_d = kpm.cuda().view(torch.uint8) if kpm is not None else None
     o, lse, mb = ops.attn_fwd(qd, kvd[:, :d], kvd[:, d:], B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff, want_bits=True)
     dq = torch.empty_like(qd); dkv = torch.empty_like(kvd)
+    import hri_emo_amd._ops as _o
+    _orig_empty_like = torch.empty_like
     ops.attn_bwd(qd, kvd[:, :d], kvd[:, d:], o, dod, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm_d, p, seed, site, boff, mask_bits=mb if use_bits else None)
+    delta = ops.attn_bwd.last_delta.cpu()
+    dref = (dob.float() * o.float().cpu()).view(B, Lq, H, hd).sum(-1).permute(0, 2, 1) * (1.0 / hashrng.inv_keep(p) if p > 0 else 1.0)
+    de = (delta - dref).abs()
+    print(f"  delta: max err {de.max():.4f} (ref max {dref.abs().max():.2f}); rows off by > 0.05: {(de > 0.05).nonzero().tolist()[:12]}")
     refs = dict(dq=q.grad.transpose(1, 2).reshape(B, Lq, H, hd), dk=k.grad.transpose(1, 2).reshape(B, Lk, H, hd), dv=v.grad.transpose(1, 2).reshape(B, Lk, H, hd))
     gots = dict(dq=dq.float().cpu().view(B, Lq, H, hd), dk=dkv[:, :d].float().cpu().view(B, Lk, H, hd), dv=dkv[:, d:].float().cpu().view(B, Lk, H, hd))
+    badq = ((gots["dq"] - refs["dq"]).abs().amax(-1) > 3e-2 * max(1.0, refs["dq"].abs().max().item())).nonzero().tolist()   # (b, q, h)
+    badk = ((gots["dk"] - refs["dk"]).abs().amax(-1) > 3e-2 * max(1.0, refs["dk"].abs().max().item())).nonzero().tolist()   # (b, key, h)
+    pairs = [(b1, h1, q1, k2) for (b1, q1, h1) in badq for (b2, k2, h2) in badk if b1 == b2 and h1 == h2]
+    for (b1, h1, q1, k2) in pairs[:12]:
+        kp = bool(keep[b1, h1, q1, k2]) if keep is not None else None
+        print(f"   pair b{b1} h{h1} q{q1} key{k2}: keep={kp} p={float(pr[b1, h1, q1, k2]):.3f} row max p={float(pr[b1, h1, q1].max()):.3f} dropped-in-row={int((keep[b1, h1, q1] == 0).sum()) if keep is not None else 0}")
     print(f"case B{B} H{H} Lq{Lq} Lk{Lk} hd{hd} masked={masked} p={p} bits={use_bits} fused_env={os.environ.get('HRIEMO_ATTN_FUSED_BWD')}")
     for n in refs:
         e = (gots[n] - refs[n]).abs()
@@ -41,5 +53,5 @@ def run(B, H, Lq, Lk, hd, masked, p, use_bits=True):
             idx = bad.nonzero()
             print("    bad (b,row,h):", sorted(set((int(x[0]), int(x[1]), int(x[2])) for x in idx))[:30])
             if kpm is not None: print("    lens of bad b:", [int(lens[b]) for b in sorted(set(idx[:, 0].tolist()))[:20]])
-for args in [(64, 8, 400, 128, 96, False, 0.1, True), (64, 8, 128, 128, 96, False, 0.1, True)]:
+for args in [(64, 8, 128, 128, 96, False, 0.1, True), (64, 8, 128, 128, 96, False, 0.1, False), (64, 8, 128, 128, 96, False, 0.0, True)]:
     run(*args)
