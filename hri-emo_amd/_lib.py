@@ -24,6 +24,7 @@ _SIGS = {
     "hriemo_attn_bwd_dq_colsum_rows": ("iiiii", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
+    "hriemo_add_ln_fwd_mx8": ("pppppppppiiffQpIlpplp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),
     "hriemo_add_ln_bwd": ("ppppppppppppiiifQpIlpp", "i"),
     "hriemo_colsum_workspace_bytes": ("ii", "l"),

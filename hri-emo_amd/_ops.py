@@ -316,9 +316,18 @@ def gemm_mode():
     return GEMM_MODE
 
 
-def mx8_ok(K, N):
-    """shapes the scaled-MFMA kernel takes (a 128-deep step per MFMA); anything else stays on the bf16 GEMM"""
-    return K % 128 == 0 and N % 8 == 0
+MX_MIN_ROWS = 1024     # below this a GEMM is latency-bound (decoder queries, gate MLP): fp8 operands buy nothing there
+
+
+def mx8_ok(K, N, M):
+    """shapes the scaled-MFMA path takes (a 128-deep step per MFMA, enough rows to be throughput-bound); anything else stays on
+    the bf16 GEMM"""
+    return K % 128 == 0 and N % 8 == 0 and M >= MX_MIN_ROWS
+
+
+def want_mx_copy(M, d):
+    """should a LayerNorm also emit the MX-fp8 copy of its [M, d] output (it feeds projection / FFN GEMMs)?"""
+    return gemm_mode() == "mx_fp8" and d % 128 == 0 and M >= MX_MIN_ROWS
 
 
 def quant_mx8(x):
@@ -361,16 +370,28 @@ def mx8_shadow(sh, p, rows=None):
 
 
 class Operand:
-    """A GEMM input in the formats the forward may want: the bf16 rows and, lazily and at most once, their MX-fp8 form."""
+    """A GEMM input in the formats the forward may want: the bf16 rows and, lazily and at most once, their MX-fp8 form
+    (handed over by the producing LayerNorm when it emitted one)."""
     __slots__ = ("x", "_q")
 
-    def __init__(self, x):
-        self.x, self._q = x, None
+    def __init__(self, x, q=None):
+        self.x, self._q = x, q
 
     def q(self):
         if self._q is None:
             self._q = quant_mx8(self.x)
         return self._q
+
+
+def mx_of(t):
+    """the MX-fp8 copy a producing LayerNorm attached to its output tensor (None if there is none)"""
+    return getattr(t, "_hriemo_mx", None)
+
+
+def tag_mx(t, mx):
+    if mx is not None:
+        t._hriemo_mx = mx
+    return t
 
 
 def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False):
@@ -379,7 +400,7 @@ def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False):
     K = x.shape[1]
     N = (rows[1] - rows[0]) if rows is not None else w.shape[0]
     b = bias if rows is None or bias is None else bias[rows[0]:rows[1]]
-    if gemm_mode() == "mx_fp8" and mx8_ok(K, N):
+    if gemm_mode() == "mx_fp8" and mx8_ok(K, N, x.shape[0]):
         xq, xs = xop.q() if isinstance(xop, Operand) else quant_mx8(x)
         wq, ws = mx8_shadow(sh, w, rows)
         return linear_fwd_mx8(xq, xs, wq, ws, b, relu=relu, out_f32=out_f32)
@@ -460,14 +481,21 @@ def attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off):
     return out
 
 
-def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False):
+def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False, want_mx=False):
     """y = LN(x + drop(g)); x32 = fp32 twin of the residual stream (used instead of x when given);
-    want32 -> also return the fp32 twin of y."""
+    want32 -> also return the fp32 twin of y; want_mx -> also the MX-fp8 copy (bytes, scales) of y as a 5th result."""
     M, d = g.shape
     y = torch.empty((M, d), dtype=BF16, device=g.device)
     y32 = torch.empty((M, d), dtype=torch.float32, device=g.device) if want32 else None
     mean = torch.empty(M, dtype=torch.float32, device=g.device)
     rstd = torch.empty(M, dtype=torch.float32, device=g.device)
+    if want_mx:
+        ld = _lib.lib().hriemo_mx8_scale_ld(M)
+        yq = torch.empty((M, d), dtype=torch.uint8, device=g.device)
+        ys = torch.empty((d // 32, ld), dtype=torch.uint8, device=g.device)
+        _lib.call("hriemo_add_ln_fwd_mx8", _p(g), _p(x), _p(x32), _p(gamma), _p(beta), _p(y), _p(y32), _p(mean), _p(rstd), M, d,
+                  _EPS, float(p), seed, _p(seed_word(g.device)), site, row_off, _p(yq), _p(ys), ld, _stream())
+        return y, y32, mean, rstd, (yq, ys)
     _lib.call("hriemo_add_ln_fwd", _p(g), _p(x), _p(x32), _p(gamma), _p(beta), _p(y), _p(y32), _p(mean), _p(rstd), M, d,
               _EPS, float(p), seed, _p(seed_word(g.device)), site, row_off, _stream())
     return y, y32, mean, rstd
@@ -613,17 +641,18 @@ class SelfAttnLN(torch.autograd.Function):
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
-        qkv = proj_fwd(x2, sh, w_in, w_in16, b_in)
+        qkv = proj_fwd(Operand(x2, mx_of(x)), sh, w_in, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse, mbits = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off, want_bits=True)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN,
+                                             want_mx=want_mx_copy(M, d))
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
-        return y.view(B, L, d), (y32.view(B, L, d) if y32 is not None else None), probs
+        return tag_mx(y.view(B, L, d), mx[0] if mx else None), (y32.view(B, L, d) if y32 is not None else None), probs
 
     @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
@@ -671,18 +700,19 @@ class CrossAttnLN(torch.autograd.Function):
         x32v = xq32.view(B * Lq, d) if xq32 is not None else None
         xkv2 = _contig_bf16(xkv).view(B * Lk, d)
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
-        q = proj_fwd(xq2, sh, w_in, w_in16, b_in, rows=(0, d))
-        kv = proj_fwd(xkv2, sh, w_in, w_in16, b_in, rows=(d, 3 * d))
+        q = proj_fwd(Operand(xq2, mx_of(xq)), sh, w_in, w_in16, b_in, rows=(0, d))
+        kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
         o, lse, mbits = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=True)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN)
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN,
+                                             want_mx=want_mx_copy(B * Lq, d))
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
-        return y.view(B, Lq, d), (y32.view(B, Lq, d) if y32 is not None else None), probs
+        return tag_mx(y.view(B, Lq, d), mx[0] if mx else None), (y32.view(B, Lq, d) if y32 is not None else None), probs
 
     @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
@@ -732,18 +762,19 @@ class FFNLN(torch.autograd.Function):
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
         w1_16, w2_16 = sh.get(w1), sh.get(w2)
-        h = proj_fwd(x2, sh, w1, w1_16, b1, relu=True)
+        h = proj_fwd(Operand(x2, mx_of(x)), sh, w1, w1_16, b1, relu=True)
         hd_ = h
         if p_mid > 0:
             hd_ = torch.empty_like(h)
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
         g = proj_fwd(hd_, sh, w2, w2_16, b2)
-        y, y32, mean, rstd = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN)
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN,
+                                             want_mx=want_mx_copy(M, d))
         ctx.save_for_backward(x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
         ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)
         ctx.params = (w1, b1, w2, b2, gamma, beta)
-        return y.view(B, L, d), (y32.view(B, L, d) if y32 is not None else None)
+        return tag_mx(y.view(B, L, d), mx[0] if mx else None), (y32.view(B, L, d) if y32 is not None else None)
 
     @staticmethod
     def backward(ctx, dy, dy32):

@@ -105,6 +105,30 @@ static inline DropCfg make_drop(float p, uint64_t seed, uint32_t site) {
   return d;
 }
 
+// ---------------------------------------------------------------- MX-fp8 block quantiser (gemm_mx8.hip, rowops.hip)
+// 8 consecutive fp32 values of this lane; the 32-element block is this lane and its three neighbours (lane ^ 1, ^ 2, ^ 3).
+// Returns the 8 e4m3 bytes and the biased E8M0 scale exponent e: scale 2^(e-127) = the smallest power of two that brings
+// the block maximum inside e4m3's finite range (448), computed exactly from the bits: amax = 1.m x 2^Ea fits under
+// 1.75 x 2^(E+8) iff E >= Ea - 8 (1.m <= 1.75) or E >= Ea - 7 (1.m > 1.75).  All 64 lanes must call it (shuffles).
+__device__ __forceinline__ __attribute__((ext_vector_type(2))) int mx8_block(const float (&f)[8], int& e_out) {
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1));
+  amax = fmaxf(amax, __shfl_xor(amax, 2));
+  const unsigned ab = __float_as_uint(amax);
+  int e = (int)(ab >> 23) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);
+  e = amax == 0.f ? 0 : (e < 1 ? 1 : (e > 253 ? 253 : e));
+  const float inv = amax == 0.f ? 0.f : __uint_as_float((unsigned)(254 - e) << 23);     // 2^-(e-127)
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, w1, true);
+  e_out = e;
+  return (__attribute__((ext_vector_type(2))) int){w0, w1};
+}
+
 // ---------------------------------------------------------------- small vector helpers
 __device__ __forceinline__ void bf8_to_f32(const bf16x8& v, float* f) {
 #pragma unroll

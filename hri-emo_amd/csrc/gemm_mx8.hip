@@ -254,63 +254,41 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
 // X[M][K] (bf16 or fp32) -> Xq[M][K] e4m3 bytes + S[K/32][lds] E8M0 bytes.  Per 32-element block: scale 2^e with
 // e = ceil(log2(amax / 448)) (the smallest power of two that brings the block inside e4m3's finite range, so nothing
 // saturates), elements = round-to-nearest-even(x * 2^-e).  amax == 0 -> e = -127 (byte 0), elements 0.
-// One wave per row (8 elements per lane and pass), 64 rows per block; the block's scale bytes are staged in LDS and leave
-// as 64-byte segments of the k-block-major scale rows.
-template <typename TIN>
+// One wave per row, every 16-byte chunk of the row in flight at once (NCH chunks per lane); a 32-block is 4 neighbouring
+// lanes (two xor-shuffles).  The same block code is used by the fused LayerNorm output (rowops.hip).
+template <typename TIN, int NCH>
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const TIN* __restrict__ X, long ldx, int M, int K, uint8_t* __restrict__ Q, long ldq,
                                                         uint8_t* __restrict__ S, long lds_) {
-  extern __shared__ __attribute__((aligned(16))) char smem_q[];     // [K/32][64]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = blockIdx.x * 64;
-  const int nkb = K >> 5;
-  for (int rr = wave; rr < 64; rr += 4) {
-    const int row = row0 + rr;
-    if (row >= M) {                                 // rows past the edge: neutral scale bytes (never used by a stored output)
-      for (int kb = lane; kb < nkb; kb += 64) smem_q[kb * 64 + rr] = 127;
-      continue;
-    }
-    for (int c0 = 0; c0 < K; c0 += 512) {
-      const int c = c0 + lane * 8;
-      float f[8];
-      if (c < K) {
+  const int nchunk = K >> 3;
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    float f[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
         if constexpr (sizeof(TIN) == 2) {
-          bf8_to_f32(*(const bf16x8*)((const bf16_t*)X + (long)row * ldx + c), f);
+          bf8_to_f32(*(const bf16x8*)((const bf16_t*)X + row * ldx + ch * 8), f[c]);
         } else {
-          const f32x4 a = *(const f32x4*)((const float*)X + (long)row * ldx + c), b = *(const f32x4*)((const float*)X + (long)row * ldx + c + 4);
-          f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+          const f32x4 a = *(const f32x4*)((const float*)X + row * ldx + ch * 8), b = *(const f32x4*)((const float*)X + row * ldx + ch * 8 + 4);
+          f[c][0] = a[0]; f[c][1] = a[1]; f[c][2] = a[2]; f[c][3] = a[3]; f[c][4] = b[0]; f[c][5] = b[1]; f[c][6] = b[2]; f[c][7] = b[3];
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      }
-      float amax = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
-      amax = fmaxf(amax, __shfl_xor(amax, 1));
-      amax = fmaxf(amax, __shfl_xor(amax, 2));        // 4 lanes x 8 elements = one 32-block
-      // e = ceil(log2(amax / 448)) exactly, from the bits: amax = 1.m x 2^Ea fits under 448 x 2^e = 1.75 x 2^(e+8)
-      // iff e >= Ea - 8 (1.m <= 1.75) or e >= Ea - 7 (1.m > 1.75)
-      const unsigned ab = __float_as_uint(amax);
-      int e = (int)(ab >> 23) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);     // biased (E8M0) exponent of the scale
-      e = amax == 0.f ? 0 : (e < 1 ? 1 : (e > 253 ? 253 : e));
-      const float inv = amax == 0.f ? 0.f : __uint_as_float((unsigned)(254 - e) << 23);     // 2^-(e-127)
-      if (c < K) {
-        int w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, w1, true);
-        typedef __attribute__((ext_vector_type(2))) int i32x2;
-        *(i32x2*)(Q + (long)row * ldq + c) = (i32x2){w0, w1};
-        if ((lane & 3) == 0) smem_q[(c >> 5) * 64 + rr] = (char)e;
+        for (int j = 0; j < 8; ++j) f[c][j] = 0.f;
       }
     }
-  }
-  __syncthreads();
-  // scale bytes out: [nkb][64] -> S[kb][row0 .. row0+63], 4 bytes per thread-iteration (the scale rows are padded to 256)
-  for (int idx = threadIdx.x; idx < nkb * 16; idx += 256) {
-    const int kb = idx >> 4, part = idx & 15;
-    *(unsigned*)(S + (long)kb * lds_ + row0 + part * 4) = *(const unsigned*)(smem_q + kb * 64 + part * 4);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      typedef __attribute__((ext_vector_type(2))) int i32x2;
+      int e;
+      const i32x2 w = mx8_block(f[c], e);
+      if (ch < nchunk) {
+        *(i32x2*)(Q + row * ldq + ch * 8) = w;
+        if ((lane & 3) == 0) S[(long)(ch >> 2) * lds_ + row] = (uint8_t)e;
+      }
+    }
   }
 }
 
@@ -380,13 +358,22 @@ extern "C" long hriemo_mx8_scale_ld(int rows) { return ((long)rows + 255) / 256 
 
 extern "C" int hriemo_quant_mx8(const void* X, long ldx, int src_is_f32, int M, int K, void* Xq, long ldq, void* S, long lds_,
                                 hipStream_t st) {
-  HRIEMO_CHECK(M > 0 && K > 0 && K % 32 == 0 && K <= 32768, "quant_mx8: K=%d must be a positive multiple of 32 (<= 32768)", K);
+  HRIEMO_CHECK(M > 0 && K > 0 && K % 32 == 0 && K <= 4096, "quant_mx8: K=%d must be a positive multiple of 32 (<= 4096)", K);
   HRIEMO_CHECK(ldx % 8 == 0 && ldq % 8 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Xq % 8) == 0, "quant_mx8: unaligned operand");
   HRIEMO_CHECK(lds_ % 256 == 0 && lds_ >= M && ((uintptr_t)S % 4) == 0, "quant_mx8: scale rows must be padded to a multiple of 256");
-  const int grid = (M + 63) / 64, smem = (K / 32) * 64;
+  const int nch = (K / 8 + 63) / 64;
+  int grid = (M + 3) / 4;
+  if (grid > 4096) grid = 4096;
   hriemo_prof_begin(HP_ROWOPS, st);
-  if (src_is_f32) hipLaunchKernelGGL((quant_mx8_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)X, ldx, M, K, (uint8_t*)Xq, ldq, (uint8_t*)S, lds_);
-  else hipLaunchKernelGGL((quant_mx8_kernel<bf16_t>), dim3(grid), dim3(256), smem, st, (const bf16_t*)X, ldx, M, K, (uint8_t*)Xq, ldq, (uint8_t*)S, lds_);
+#define QCALL(T, N) hipLaunchKernelGGL((quant_mx8_kernel<T, N>), dim3(grid), dim3(256), 0, st, (const T*)X, ldx, M, K, (uint8_t*)Xq, ldq, (uint8_t*)S, lds_)
+#define QDISP(T)                               \
+  if (nch <= 1) { QCALL(T, 1); }               \
+  else if (nch <= 2) { QCALL(T, 2); }          \
+  else if (nch <= 4) { QCALL(T, 4); }          \
+  else { QCALL(T, 8); }
+  if (src_is_f32) { QDISP(float) } else { QDISP(bf16_t) }
+#undef QDISP
+#undef QCALL
   HRIEMO_LAUNCH_CHECK("quant_mx8_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (double)M * K * (src_is_f32 ? 5 : 3) + (double)M * K / 32);
   return 0;

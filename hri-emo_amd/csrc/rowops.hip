@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ beta, bf16_t* __restrict__ Y,
                                                          float* __restrict__ Y32, float* __restrict__ mean_o,
                                                          float* __restrict__ rstd_o, int M, int d, float eps, RowDrop dr,
-                                                         long row_offset) {
+                                                         long row_offset, uint8_t* __restrict__ Yq, uint8_t* __restrict__ SY, long ldsy) {
   const uint32_t key32 = row_key(dr);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = d >> 3;
@@ -142,10 +142,29 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j)
           o[j] = (s[c][j] - mu) * rstd * (HOIST ? gm8[HOIST ? c : 0][j] : gamma[ch * 8 + j]) + (HOIST ? bt8[HOIST ? c : 0][j] : beta[ch * 8 + j]);
-        *(bf16x8*)(Y + row * d + ch * 8) = f32_to_bf8(o);
+        const bf16x8 ob = f32_to_bf8(o);
+        *(bf16x8*)(Y + row * d + ch * 8) = ob;
         if (Y32 != nullptr) {
           *(f32x4*)(Y32 + row * d + ch * 8) = (f32x4){o[0], o[1], o[2], o[3]};
           *(f32x4*)(Y32 + row * d + ch * 8 + 4) = (f32x4){o[4], o[5], o[6], o[7]};
+        }
+        if (Yq != nullptr) bf8_to_f32(ob, s[c]);      // the MX-fp8 copy quantises the bf16 output (what a separate pass would read)
+      }
+    }
+    if (Yq != nullptr) {                              // kernel-uniform: MX-fp8 copy of y for the next GEMM (d % 32 == 0)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch >= nchunk) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[c][j] = 0.f;
+        }
+        typedef __attribute__((ext_vector_type(2))) int i32x2;
+        int e;
+        const i32x2 w = mx8_block(s[c], e);
+        if (ch < nchunk) {
+          *(i32x2*)(Yq + row * d + ch * 8) = w;
+          if ((lane & 3) == 0) SY[(long)(ch >> 2) * ldsy + row] = (uint8_t)e;
         }
       }
     }
@@ -736,18 +755,32 @@ static int lnb_cap(int d) {
   return cache[slot];
 }
 
-extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
-                                 float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
-                                 const unsigned long long* seed_dev, unsigned site, long row_offset, hipStream_t st) {
+static int add_ln_fwd_impl(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                           float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                           const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy, hipStream_t st) {
   if (check_rows(M, d)) return 1;
+  HRIEMO_CHECK(Yq == nullptr || (d % 32 == 0 && SY != nullptr && ldsy >= M), "add_ln_fwd: the MX-fp8 copy needs d %% 32 == 0 and a scale buffer");
   RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset)
+#define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset, (uint8_t*)Yq, (uint8_t*)SY, ldsy)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("add_ln_fwd_kernel");
-  hriemo_prof_end(HP_ROWOPS, st, ((X32 ? 3.0 : (X ? 2.0 : 1.0)) + 1.0 + (Y32 ? 2.0 : 0.0)) * M * d * 2);
+  hriemo_prof_end(HP_ROWOPS, st, ((X32 ? 3.0 : (X ? 2.0 : 1.0)) + 1.0 + (Y32 ? 2.0 : 0.0) + (Yq ? 0.5 : 0.0)) * M * d * 2);
   return 0;
+}
+extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                                 float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                                 const unsigned long long* seed_dev, unsigned site, long row_offset, hipStream_t st) {
+  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, nullptr, nullptr, 0, st);
+}
+// same, plus the MX-fp8 copy of Y (bytes [M][d], scales [d/32][ldsy]) for the next projection / FFN GEMM (hriemo_gemm_mx8)
+extern "C" int hriemo_add_ln_fwd_mx8(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                                     float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                                     const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
+                                     hipStream_t st) {
+  HRIEMO_CHECK(Yq != nullptr, "add_ln_fwd_mx8: Yq required");
+  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, Yq, SY, ldsy, st);
 }
 
 extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)row_grid(M, lnb_cap(d)) * 3 * d + 64L * 3 * d) * 4; }

@@ -70,6 +70,10 @@ class EmotionDecoder(nn.Module):
         # fp32 twin of the broadcast queries (residual operand of the first layer; gradient flows via `out`)
         out32 = self.emotion_queries.detach().float().unsqueeze(0).expand(B, -1, -1).contiguous() if _ops.TWIN else None
         all_layers_attn = []
+        if _ops.want_mx_copy(memory16.shape[0] * memory16.shape[1], memory16.shape[2]):
+            # fp8 GEMM mode: every layer projects the same memory to K | V -- quantise it once
+            m2 = memory16 if memory16.is_contiguous() else memory16.contiguous()
+            memory16 = _ops.tag_mx(m2, _ops.quant_mx8(m2.view(-1, m2.shape[2])))
         for layer in self.layers:
             out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need)
             if need and attn_map is not None:

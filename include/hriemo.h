@@ -109,6 +109,12 @@ int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const un
 int hriemo_add_ln_fwd(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
                       float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
                       const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);
+/* same, plus the MX-fp8 copy of Y (e4m3 bytes [M][d], E8M0 scales [d/32][ldsy], d % 32 == 0): the quantiser of hriemo_quant_mx8
+ * fused into the LayerNorm that produces the next GEMM's operand (bit-identical to quantising the bf16 Y afterwards) */
+int hriemo_add_ln_fwd_mx8(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                          float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                          const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
+                          hriemo_stream_t stream);
 long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
 int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
                       const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,

@@ -47,6 +47,22 @@ def test_quantiser_matches_host_emulation_bitwise(ops, M, K, src):
     assert rel <= 2 ** -4, rel                            # e4m3: 3 mantissa bits, and the block maximum never saturates
 
 
+@pytest.mark.parametrize("M,d,p", [(300, 768, 0.1), (1030, 1024, 0.0), (64, 128, 0.1), (17, 2048, 0.0)])
+def test_layernorm_fused_mx8_copy_equals_separate_quantiser(ops, M, d, p):
+    """hriemo_add_ln_fwd_mx8: the MX-fp8 copy written by the LayerNorm kernel is bit-identical to hriemo_quant_mx8 of its
+    bf16 output, and the bf16 / fp32 outputs are unchanged by asking for it."""
+    g = torch.Generator().manual_seed(M + d)
+    G, X = torch.randn(M, d, generator=g).bfloat16().cuda(), (torch.randn(M, d, generator=g) * 2).bfloat16().cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (0.1 * torch.randn(d, generator=g)).cuda()
+    y0, y032, mean0, rstd0 = ops.add_ln_fwd(G, X, gamma, beta, p, 1234, 7, 100, want32=True)
+    y1, y132, mean1, rstd1, (yq, ys) = ops.add_ln_fwd(G, X, gamma, beta, p, 1234, 7, 100, want32=True, want_mx=True)
+    assert torch.equal(y0, y1) and torch.equal(y032, y132) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    q2, s2 = ops.quant_mx8(y1)
+    assert torch.equal(yq, q2) and torch.equal(ys[:, :M], s2[:, :M])
+    q_ref, s_ref = mx8_quantize(y1.float().cpu())
+    assert torch.equal(yq.cpu(), q_ref) and torch.equal(ys[:, :M].t().cpu(), s_ref)
+
+
 MX_SHAPES = [(256, 128, 128), (200, 136, 256), (128, 384, 384), (1024, 768, 768), (64, 256, 3072), (37 * 8, 8, 128),
              (130, 2304, 768), (8192, 1024, 1024), (300, 264, 640)]
 
