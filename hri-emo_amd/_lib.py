@@ -48,6 +48,8 @@ _SIGS = {
     "hriemo_adamw_flat": ("pppplfffffifpp", "i"),
     "hriemo_masked_mean_fwd": ("ppppiiip", "i"),
     "hriemo_rowsum_f32": ("ppilp", "i"),
+    "hriemo_gate_input_pooled": ("pppiip", "i"),
+    "hriemo_fusion_loss": ("ppppiiiffpppp", "i"),
     "hriemo_scalar_gate_dx": ("pipippppiiip", "i"),
     "hriemo_fuse_bwd_dw": ("ppppiiip", "i"),
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),

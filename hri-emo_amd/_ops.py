@@ -894,11 +894,11 @@ class BetaGateFn(torch.autograd.Function):
 class LegacyBetaGateFn(torch.autograd.Function):
     """(h_fusion, beta) of the legacy scalar gate, models/beta_gate.py:60-114: masked-mean pools of the raw features,
     [a, t, |a-t|, a*t] -> Linear(4d,h) -> ReLU -> Linear(h,1) -> sigmoid = beta[B,1], h = beta*h_a[:, :L] + (1-beta)*h_t[:, :L].
-    Pooling, fusion and their backward run in the HIP kernels; the [B]-sized MLP is host-side plumbing (its local
-    graph is kept and differentiated in backward, so the big tensors see one fused gradient kernel each)."""
+    Everything runs in libhriemo.so: pooling / gate input / fusion row kernels, the MLP on hriemo_gemm_bf16 (first layer) and
+    hriemo_rowdot_* (the h -> 1 layer), like the vector gate; only [B]- and [B,h]-sized casts / masks are torch plumbing."""
 
     @staticmethod
-    def forward(ctx, h_a, h_t, w1, b1, w2, b2, kpm_a, kpm_t):
+    def forward(ctx, h_a, h_t, w1, b1, w2, b2, sh, kpm_a, kpm_t):
         _require_fp32_masters(w1, b1, w2, b2)
         _require_gpu(h_a)
         B, La, d = h_a.shape
@@ -914,25 +914,28 @@ class LegacyBetaGateFn(torch.autograd.Function):
         cnt_a, cnt_t = torch.empty(B, **f32), torch.empty(B, **f32)
         _lib.call("hriemo_masked_mean_fwd", _p(xa), _p(kpm_a), _p(a_pool), _p(cnt_a), B, La, d, st)
         _lib.call("hriemo_masked_mean_fwd", _p(xt), _p(kpm_t), _p(t_pool), _p(cnt_t), B, Lt, d, st)
-        with torch.enable_grad():
-            pa, pt = a_pool.detach().requires_grad_(True), t_pool.detach().requires_grad_(True)
-            params = [t.detach().requires_grad_(True) for t in (w1, b1, w2, b2)]
-            gin = torch.cat([pa, pt, (pa - pt).abs(), pa * pt], dim=-1)
-            beta = torch.sigmoid(F.linear(torch.relu(F.linear(gin, params[0], params[1])), params[2], params[3]))   # [B,1]
+        gin = torch.empty((B, 4 * d), dtype=BF16, device=dev)
+        _lib.call("hriemo_gate_input_pooled", _p(a_pool), _p(t_pool), _p(gin), B, d, st)
+        w1_16 = sh.get(w1)
+        hid = linear_fwd(gin, w1_16, b1, relu=True)                                        # [B, h] bf16
+        w2f, b2f = w2.detach().float().contiguous(), b2.detach().float().contiguous()
+        pre = torch.empty(B, **f32)
+        _lib.call("hriemo_rowdot_fwd", _p(hid), None, _p(w2f), _p(b2f), _p(pre), B, hid.shape[1], st)
+        beta = torch.empty((B, 1), **f32)
+        wfull1 = torch.empty((B, 1), **f32)
+        _lib.call("hriemo_sigmoid_beta", _p(pre), _p(wfull1), _p(beta), B, 1, st)          # d = 1: w == beta == sigmoid(pre)
         A = xa if La == L else xa[:, :L].contiguous()
         T = xt
-        wfull = beta.detach().expand(B, d).contiguous()
+        wfull = beta.expand(B, d).contiguous()
         H = torch.empty((B, L, d), dtype=BF16, device=dev)
         _lib.call("hriemo_fuse_fwd", _p(wfull), _p(A), _p(T), _p(H), B, L, d, st)
-        ctx.save_for_backward(A, T, cnt_a, cnt_t, kpm_a, kpm_t)
-        ctx.local = (beta, pa, pt, params)
+        ctx.save_for_backward(A, T, cnt_a, cnt_t, kpm_a, kpm_t, a_pool, t_pool, gin, hid, beta, w1_16, w2f)
         ctx.cfg = (B, La, Lt, L, d)
-        return H, beta.detach()
+        return H, beta
 
     @staticmethod
     def backward(ctx, dH, dbeta):
-        A, T, cnt_a, cnt_t, kpm_a, kpm_t = ctx.saved_tensors
-        beta, pa, pt, params = ctx.local
+        A, T, cnt_a, cnt_t, kpm_a, kpm_t, a_pool, t_pool, gin, hid, beta, w1_16, w2f = ctx.saved_tensors
         B, La, Lt, L, d = ctx.cfg
         dev = A.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -943,18 +946,62 @@ class LegacyBetaGateFn(torch.autograd.Function):
         part = torch.empty((B, nc, d), **f32)
         _lib.call("hriemo_fuse_bwd_dw", _p(dH2), _p(A), _p(T), _p(part), B, L, d, st)
         dbeta_h = torch.empty(B, **f32)
-        _lib.call("hriemo_rowsum_f32", _p(part), _p(dbeta_h), B, nc * d, st)
-        g = dbeta_h.view(B, 1)
-        if dbeta is not None:
-            g = g + dbeta.float()
-        grads = torch.autograd.grad(beta, [pa, pt] + params, g)
-        dpa, dpt = grads[0].contiguous(), grads[1].contiguous()
-        bflat = beta.detach().reshape(B).contiguous()
+        _lib.call("hriemo_rowsum_f32", _p(part), _p(dbeta_h), B, nc * d, st)               # d loss / d beta through the fusion
+        dbeta2 = dbeta.contiguous().float() if dbeta is not None else None
+        dpre16 = torch.empty((B, 1), dtype=BF16, device=dev)
+        # gate_dpre with d = 1: (dbeta_h + dbeta) * beta * (1 - beta)
+        _lib.call("hriemo_gate_dpre", _p(dbeta_h), 1, _p(dbeta2), _p(beta), _p(dpre16), B, 1, st)
+        dpre = dpre16.float().view(B)                                                      # [B]-sized plumbing
+        Hd = hid.shape[1]
+        dhid = torch.empty((B, Hd), dtype=BF16, device=dev)
+        dw2 = torch.empty((1, Hd), **f32)
+        db2 = torch.empty(1, **f32)
+        _lib.call("hriemo_rowdot_bwd", _p(dpre), _p(hid), None, _p(w2f), _p(dhid), _p(dw2), _p(db2), B, Hd, st)
+        dhid = dhid * (hid > 0)                                                            # ReLU mask, [B,h]-sized plumbing
+        dw1 = torch.empty((Hd, 4 * d), **f32)
+        linear_dw(dhid, gin, dw1)
+        db1 = torch.empty(Hd, **f32)
+        colsum(dhid, db1)
+        dgin = linear_dx(dhid, w1_16)
+        dpa, dpt = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
+        ones = torch.ones((B, 2), **f32)           # scalar_gate_dx divides by the valid counts itself
+        _lib.call("hriemo_gate_input_bwd", _p(dgin), _p(a_pool), _p(t_pool), _p(ones), _p(dpa), _p(dpt), B, d, st)
+        bflat = beta.reshape(B).contiguous()
         dxa = torch.empty((B, La, d), dtype=BF16, device=dev)
         dxt = torch.empty((B, Lt, d), dtype=BF16, device=dev)
         _lib.call("hriemo_scalar_gate_dx", _p(dH2), L, _p(bflat), 1, _p(dpa), _p(cnt_a), _p(kpm_a), _p(dxa), B, La, d, st)
         _lib.call("hriemo_scalar_gate_dx", _p(dH2), L, _p(bflat), 0, _p(dpt), _p(cnt_t), _p(kpm_t), _p(dxt), B, Lt, d, st)
-        return dxa, dxt, grads[2], grads[3], grads[4], grads[5], None, None
+        return dxa, dxt, dw1, db1, dw2, db2, None, None, None
+
+
+class FusionLossFn(torch.autograd.Function):
+    """Trainer loss with its gradients from ONE kernel (hriemo_fusion_loss): mean BCEWithLogits(logits, targets; pos_weight) +
+    reg(beta).  reg_mode 1 = -coef*mean(beta(1-beta)) (train_fusion_seq_level_decoder.py:318-326), 2 = +coef*entropy(beta)
+    (train_mosei_fusion_seq_level_decoder.py:340-347,385-386); `scale` = 1/grad_accum (:387)."""
+
+    @staticmethod
+    def forward(ctx, logits, beta, targets, pos_weight, reg_mode, reg_coef, scale):
+        _require_gpu(logits)
+        B, Ne = logits.shape
+        x, y = logits.contiguous().float(), targets.contiguous().float()
+        bt = beta.contiguous().float().view(B) if beta is not None else None
+        pw = pos_weight.contiguous().float() if pos_weight is not None else None
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty((B, Ne), dtype=torch.float32, device=x.device)
+        db = torch.empty(B, dtype=torch.float32, device=x.device) if bt is not None else None
+        _lib.call("hriemo_fusion_loss", _p(x), _p(y), _p(pw), _p(bt), B, Ne, int(reg_mode) if bt is not None else 0, float(reg_coef),
+                  float(scale), _p(loss), _p(dx), _p(db), _stream())
+        ctx.save_for_backward(dx, db)
+        ctx.shapes = (logits.shape, beta.shape if beta is not None else None, logits.dtype, beta.dtype if beta is not None else None)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, db = ctx.saved_tensors
+        ls, bs, ld, bd = ctx.shapes
+        gl = (dx * g).to(ld).view(ls)
+        gb = (db * g).to(bd).view(bs) if db is not None else None
+        return gl, gb, None, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):

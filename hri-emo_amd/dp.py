@@ -15,9 +15,16 @@ import torch.distributed as dist
 
 
 class GradBuckets:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True):
+    """comm_dtype: torch.float32 (default: the flat buffer is all-reduced in place) or torch.bfloat16: every bucket is cast to a
+    bf16 staging buffer (half the bytes on the xGMI links: 109 MB instead of 218 MB per step at cfg 2), summed by the collective in
+    bf16 and cast back into the fp32 flat buffer (the 1/N average is applied in fp32).  A bf16 sum over N <= 8 ranks adds
+    ~2^-9 relative rounding per addition on top of the bf16 backward that produced the gradients."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True, comm_dtype=torch.float32):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.comm_dtype = comm_dtype
+        self._stage = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # matrices first, in the order backward produces them (decoder first, fusion layer 0 last); every vector
         # parameter (biases, LayerNorm gain/bias) behind them: their gradients are finished by the launch-boundary
@@ -69,7 +76,14 @@ class GradBuckets:
             for st in _ops.branch_streams(self.flat.device):
                 if st != cur:
                     cur.wait_stream(st)
-        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.comm_dtype == torch.float32:
+            self._works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+        else:
+            if self._stage is None:
+                self._stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
+            st = self._stage[s:e]
+            st.copy_(self.flat[s:e])                    # fp32 -> bf16 on the launching stream, ordered before the collective
+            self._works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (s, e)))
 
     def _on_grad(self, p, from_sink=False):
         """gradient of `p` is final.  Sources: autograd's post-accumulate hook (gradients returned as tensors) and
@@ -104,8 +118,10 @@ class GradBuckets:
             for bi in range(len(self.buckets)):
                 if not self._launched[bi]:          # no hooks, or a parameter got no gradient this step
                     self._launch(bi)
-            for w in self._works:
+            for w, rng in self._works:
                 w.wait()
+                if rng is not None:                     # summed bf16 bucket back into the fp32 flat buffer
+                    self.flat[rng[0]:rng[1]].copy_(self._stage[rng[0]:rng[1]])
             self._works = []
             self._pending = [0] * len(self.buckets)
             self._launched = [False] * len(self.buckets)
@@ -136,11 +152,11 @@ class DataParallelStep:
     shadows are re-cast inside the graph so optimizer updates between replays are honoured.  The gradient
     all-reduce runs after the replay on the flat buffer."""
 
-    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True):
+    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True, comm_dtype=torch.float32):
         self.model, self.loss_fn = model, loss_fn
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap)
+        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype)
         self._graph = None
         self._static = None
         self._static_loss = None
@@ -151,12 +167,31 @@ class DataParallelStep:
             self.model.set_batch_offset(lo)
         return lo, hi
 
-    def _fwd_bwd(self, h_a, h_t, m_a, m_t, y):
-        self.buckets.zero_grad()
+    def _fwd_bwd(self, h_a, h_t, m_a, m_t, y, zero=True, scale=None):
+        if zero:
+            self.buckets.zero_grad()
         logits, beta, _ = self.model(h_a, h_t, m_a, m_t)
         loss = self.loss_fn(logits, beta, y)
+        if scale is not None:
+            loss = loss * scale
         loss.backward()
         return loss.detach()
+
+    def step_accumulated(self, micro_batches):
+        """Gradient accumulation (train_mosei_fusion_seq_level_decoder.py:387-396: loss / grad_accum, optimizer every grad_accum
+        micro-steps) under data parallelism WITHOUT a gradient exchange per micro-step: the flat buffer is zeroed once, every
+        micro-batch accumulates into it (the kernels add in place), gradient-ready notifications stay suspended until the LAST
+        micro-batch, whose backward launches the bucket all-reduces as usual.  Returns the mean of the micro-losses."""
+        k = len(micro_batches)
+        was = self.buckets.suspended
+        total = None
+        for i, mb in enumerate(micro_batches):
+            self.buckets.suspended = True if i + 1 < k else was
+            l = self._fwd_bwd(*mb, zero=(i == 0), scale=1.0 / k)
+            total = l if total is None else total + l
+        self.buckets.suspended = was
+        self.buckets.finish()
+        return total
 
     def capture(self, h_a, h_t, m_a, m_t, y):
         """Record one step on static copies of the batch tensors; later ``step()`` calls replay it."""

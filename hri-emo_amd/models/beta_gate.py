@@ -12,6 +12,7 @@ class BetaGate(nn.Module):
     def __init__(self, d_model=768, hidden_dim=256):
         super().__init__()
         self.mlp = nn.Sequential(nn.Linear(d_model * 4, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, 1))
+        self._sh = _ops.Shadows()
 
     def forward(self, h_a, h_t, mask_a=None, mask_t=None):
         out_dtype = h_a.dtype
@@ -19,5 +20,5 @@ class BetaGate(nn.Module):
         Lt = h_t.shape[1]
         kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
         h_fusion, beta = _ops.LegacyBetaGateFn.apply(h_a, h_t, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
-                                                     self.mlp[2].bias, kpm_a, kpm_t)
+                                                     self.mlp[2].bias, self._sh, kpm_a, kpm_t)
         return h_fusion.to(out_dtype), beta

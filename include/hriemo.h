@@ -161,6 +161,15 @@ int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, const float* t_
 int hriemo_masked_mean_fwd(const void* X, const unsigned char* mask, float* pooled, float* cnt, int B, int L, int d,
                            hriemo_stream_t stream);
 int hriemo_rowsum_f32(const float* x, float* out, int B, long n, hriemo_stream_t stream);
+/* gate input [a, t, |a-t|, a*t] (bf16 [B,4d]) from already pooled means: the legacy gate's MLP then runs on hriemo_gemm_bf16 +
+ * hriemo_rowdot_* like the vector gate's (models/beta_gate.py:82-93) */
+int hriemo_gate_input_pooled(const float* a_pool, const float* t_pool, void* gate_in, int B, int d, hriemo_stream_t stream);
+/* Trainer losses, value and gradients in one launch ([B,N_e]-sized): mean BCEWithLogits(logits, targets; pos_weight (may be NULL))
+ * + reg(beta) (reg_mode 0 none; 1: -coef*mean(beta(1-beta)), scripts/fusion/train_fusion_seq_level_decoder.py:318-326; 2: +coef*mean
+ * binary entropy of clamp(beta,1e-8,1-1e-8), train_mosei_fusion_seq_level_decoder.py:340-347,385-386,569), everything times `scale`
+ * (1/grad_accum).  Writes loss[1], dlogits[B,N_e], dbeta[B] (dbeta may be NULL). */
+int hriemo_fusion_loss(const float* logits, const float* targets, const float* pos_weight, const float* beta, int B, int Ne,
+                       int reg_mode, float reg_coef, float scale, float* loss, float* dlogits, float* dbeta, hriemo_stream_t stream);
 int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, const float* dpool, const float* cnt,
                           const unsigned char* mask, void* dX, int B, int L, int d, hriemo_stream_t stream);
 /* Trainer step off the timed path, scripts/fusion/train_fusion_seq_level_decoder.py:332-334: clip_grad_norm_(5.0) +

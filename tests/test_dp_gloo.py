@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_q):
+def _worker(rank, world, port, out_q, mode="plain"):
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,11 +30,17 @@ def _worker(rank, world, port, out_q):
     m_a = torch.arange(Ta)[None] >= torch.randint(Ta // 2, Ta + 1, (B, 1), generator=g)
     m_t = torch.arange(Tt)[None] >= torch.randint(Tt // 2, Tt + 1, (B, 1), generator=g)
     y = (torch.rand(B, 3, generator=g) < 0.3).float()
-    dp = DataParallelStep(model, fusion_step_loss, bucket_bytes=64 << 10, overlap=True)   # several buckets
+    comm = torch.bfloat16 if mode == "bf16" else torch.float32
+    dp = DataParallelStep(model, fusion_step_loss, bucket_bytes=64 << 10, overlap=True, comm_dtype=comm)   # several buckets
     lo, hi = dp.set_global_batch(B)
     assert (lo, hi) == shard_bounds(B, rank, world)
     for _ in range(2):                                   # two steps: buckets reset correctly
-        loss = dp.step(h_a[lo:hi], h_t[lo:hi], m_a[lo:hi], m_t[lo:hi], y[lo:hi])
+        if mode == "accum":                              # two micro-batches per rank, ONE exchange (gradient accumulation)
+            mid = (lo + hi) // 2
+            # mean-reduced losses: each micro-batch holds half of this rank's utterances, so its loss is scaled by 1/2
+            loss = dp.step_accumulated([(h_a[a:b], h_t[a:b], m_a[a:b], m_t[a:b], y[a:b]) for a, b in ((lo, mid), (mid, hi))])
+        else:
+            loss = dp.step(h_a[lo:hi], h_t[lo:hi], m_a[lo:hi], m_t[lo:hi], y[lo:hi])
     grads = {n: p.grad.clone().numpy() for n, p in model.named_parameters()}   # by value through the queue
     flat_ok = all(p.grad.data_ptr() >= dp.buckets.flat.data_ptr() for p in model.parameters())
     if rank == 0:
@@ -43,14 +49,17 @@ def _worker(rank, world, port, out_q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_rank_step_on_concatenated_batch():
+@pytest.mark.parametrize("mode", ["plain", "bf16", "accum"])
+def test_two_rank_step_equals_single_rank_step_on_concatenated_batch(mode):
+    """plain: fp32 buckets; bf16: gradients cross the wire as bf16 (summed in bf16, averaged in fp32); accum: two micro-batches
+    per rank accumulate locally and are exchanged once (train_mosei_fusion_seq_level_decoder.py:387-396)."""
     sys.path.insert(0, REPO)
     from oracle import hri_emo_oracle as O
     from hri_emo_amd.train import fusion_step_loss
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + {"plain": 0, "bf16": 7, "accum": 13}[mode]) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     grads, loss0, nbuckets, flat_ok = q.get(timeout=240)
@@ -72,7 +81,8 @@ def test_two_rank_step_equals_single_rank_step_on_concatenated_batch():
     for n, p in model.named_parameters():
         ref = p.grad
         err = (torch.from_numpy(grads[n]) - ref).abs().max().item()
-        assert err <= 1e-5 * max(1.0, ref.abs().max().item()) + 1e-7, (n, err)
+        tol = 1e-2 if mode == "bf16" else 1e-5          # bf16 on the wire: 2^-8 per value, two ranks
+        assert err <= tol * max(1.0, ref.abs().max().item()) + 1e-7, (mode, n, err)
 
 
 def test_shard_bounds():

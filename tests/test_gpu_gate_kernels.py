@@ -270,3 +270,34 @@ def test_dropout_kernel_exact_vs_hash_replica(lib, M, N, p, roff):
     lib.call("hriemo_dropout_bf16", P(X_d), P(Y2), M, N, float(p), seed, P(word), site, roff, ST())
     lib.call("hriemo_dropout_bf16", P(X_d), P(Y3), M, N, float(p), seed + 977, None, site, roff, ST())
     assert torch.equal(Y2, Y3) and not torch.equal(Y2, Y)
+
+
+@pytest.mark.parametrize("B,Ne,mode,coef,pw,scale", [(64, 6, 1, 0.01, False, 1.0), (8, 4, 2, 0.05, True, 0.25), (3, 7, 0, 0.0, True, 1.0),
+                                                      (512, 6, 2, 0.01, False, 0.5), (1, 1, 1, 0.01, False, 1.0)])
+def test_fusion_loss_kernel_value_and_gradients(lib, B, Ne, mode, coef, pw, scale):
+    """hriemo_fusion_loss through the C ABI and through the autograd Function against torch's BCEWithLogitsLoss(pos_weight) +
+    the two trainers' beta regularisers (train_fusion_seq_level_decoder.py:318-326; train_mosei_...:340-347,385-387,569)."""
+    from hri_emo_amd import _ops
+    g = torch.Generator().manual_seed(B * 10 + Ne)
+    x = (torch.randn(B, Ne, generator=g) * 3).requires_grad_(True)
+    y = (torch.rand(B, Ne, generator=g) < 0.3).float()
+    beta = torch.rand(B, 1, generator=g).requires_grad_(True)
+    with torch.no_grad():
+        if B >= 3:
+            beta[0, 0], beta[1, 0] = 0.0, 1.0          # clamped ends of the entropy: zero gradient there
+    posw = (0.5 + 3 * torch.rand(Ne, generator=g)) if pw else None
+    ref = F.binary_cross_entropy_with_logits(x, y, pos_weight=posw)
+    if mode == 1:
+        ref = ref - coef * (beta * (1 - beta)).mean()
+    elif mode == 2:
+        b = torch.clamp(beta, 1e-8, 1 - 1e-8)
+        ref = ref + coef * (-(b * torch.log(b) + (1 - b) * torch.log(1 - b))).mean()
+    ref = ref * scale
+    ref.backward()
+    xd, bd = x.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+    loss = _ops.FusionLossFn.apply(xd, bd if mode else None, y.cuda(), posw.cuda() if pw else None, mode, coef, scale)
+    (loss * 3.0).backward()                             # an outer factor (GradScaler) must flow through
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert (xd.grad.cpu() / 3.0 - x.grad).abs().max() <= 2e-6 * max(1.0, x.grad.abs().max().item())
+    if mode:
+        assert (bd.grad.cpu() / 3.0 - beta.grad).abs().max() <= 1e-5 * max(1e-3, beta.grad.abs().max().item())

@@ -127,12 +127,13 @@ def _err(a, b):
 
 @pytest.mark.parametrize("B,Ta,Tt,d,ne,lf,ld", [(2, 400, 128, 1024, 7, 4, 2),       # BASELINE configs[4] dimensions
                                                 (3, 100, 40, 768, 6, 2, 2), (4, 32, 16, 128, 4, 2, 2)])
-def test_fusion_mx_fp8_vs_oracle_and_emulated_yardstick(ops, B, Ta, Tt, d, ne, lf, ld):
+def test_fusion_mx_fp8_vs_oracle_and_emulated_yardstick(ops, monkeypatch, B, Ta, Tt, d, ne, lf, ld):
     """Stated tolerance of the fp8 GEMM mode: max|out - fp32 oracle| <= 6e-2 * max(1, max|ref|) on logits / beta / z, AND
     within 2.5x the yardstick: the oracle evaluated with the SAME quantiser on both operands of every projection / FFN GEMM
     (oracle.LINEAR_OPERAND_HOOK = mx8_roundtrip), whose own distance from the fp32 oracle is what e4m3 operands cost the
     reference path itself.  The HIP result must also stay within 1.5x that distance of the emulated reference."""
     import hri_emo_amd as H
+    monkeypatch.setattr(ops, "MX_MIN_ROWS", 1)      # the product gates fp8 on >= 1024 rows (throughput-bound GEMMs); here every GEMM takes it
     torch.manual_seed(1234)
     kw = dict(d_model=d, num_emotions=ne, n_heads=8, dropout=0.1, num_layers_fusion=lf, num_layers_decoder=ld)
     ref = O.FusionWithEmotionDecoder(**kw).eval()
@@ -164,9 +165,10 @@ def test_fusion_mx_fp8_vs_oracle_and_emulated_yardstick(ops, B, Ta, Tt, d, ne, l
         assert not torch.equal(g8.float().cpu(), g16.float().cpu()) or d % 128 != 0, "fp8 mode must actually change the GEMMs"
 
 
-def test_fusion_mx_fp8_trains(ops):
+def test_fusion_mx_fp8_trains(ops, monkeypatch):
     """forward on fp8 operands, backward on the bf16 GEMMs: gradients finite and close to the bf16 mode's (straight-through)."""
     import hri_emo_amd as H
+    monkeypatch.setattr(ops, "MX_MIN_ROWS", 1)
     torch.manual_seed(7)
     m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
     h_a, h_t, m_a, m_t = _rand_batch(4, 48, 24, 256, 9)

@@ -143,7 +143,7 @@ GRAD_FACTOR = 3.0          # ... or this many times the reference path's own bf1
 def assert_per_parameter_grads(gm, gy, gr, exceptions=(), what=""):
     """EVERY parameter n: rel-L2(mine[n], fp32 oracle[n]) <= max(floor, GRAD_FACTOR * rel-L2(yardstick[n], fp32 oracle[n])),
     the yardstick being the reference path itself in bf16 (torch CPU autocast of the oracle on the same weights).
-    floor = max(GRAD_FLOOR, 90th percentile of the yardstick's own per-parameter errors): with well-conditioned (default
+    floor = max(GRAD_FLOOR, 1.25 x the 90th percentile of the yardstick's own per-parameter errors): with well-conditioned (default
     init) weights that is 4e-2; with the ill-conditioned closed-form fixture weights the reference-in-bf16 itself is 5-9 %
     off on most parameters and the floor follows it.  No parameter is exempt unless named in `exceptions` (name -> bound)."""
     exceptions = dict(exceptions)
@@ -165,7 +165,7 @@ def assert_per_parameter_grads(gm, gy, gr, exceptions=(), what=""):
             km, ky = gm[n][d3:2 * d3].float().norm().item(), gy[n][d3:2 * d3].float().norm().item()
             assert km <= max(3.0 * ky, 0.1 * qv), (what, n, "noise in the zero-gradient K third", km, ky, qv)
     ys = sorted(rel(gy[n], gr[n], n) for n in gr)
-    floor = max(GRAD_FLOOR, ys[len(ys) * 9 // 10])
+    floor = max(GRAD_FLOOR, 1.25 * ys[len(ys) * 9 // 10])
     rows, bad = [], []
     for n in gr:
         em, ey = rel(gm[n], gr[n], n), rel(gy[n], gr[n], n)
@@ -754,3 +754,69 @@ def test_bench_two_rank_control_flow_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["launch"] == "eager" and d["value"] > 0
     assert "roofline" in d and d["roofline"]["frac"] > 0 and d["cross_attention"] is not None
+
+
+def _nccl_worker(rank, world, port, q):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        import hri_emo_amd as H
+        from hri_emo_amd.dp import DataParallelStep
+        from hri_emo_amd.train import fusion_step_loss
+        torch.manual_seed(3)
+        m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+        h_a, h_t, m_a, m_t = _rand_batch(8, 48, 24, 128, 31)
+        y = (torch.rand(8, 4, generator=torch.Generator().manual_seed(5)) < 0.3).float()
+        res = {}
+        for name, kw in (("eager_overlap_fp32", dict(overlap=True)), ("eager_overlap_bf16", dict(overlap=True, comm_dtype=torch.bfloat16)),
+                         ("replay_then_exchange", dict(overlap=False))):
+            dp = DataParallelStep(m, fusion_step_loss, bucket_bytes=256 << 10, **kw)
+            lo, hi = dp.set_global_batch(8)
+            b = (h_a[lo:hi].cuda().bfloat16(), h_t[lo:hi].cuda().bfloat16(), m_a[lo:hi].cuda(), m_t[lo:hi].cuda(), y[lo:hi].cuda())
+            dp.step(*b)
+            if name == "replay_then_exchange":
+                dp.capture(*b)
+            for _ in range(2):
+                dp.step(*b)
+            torch.cuda.synchronize()
+            res[name] = dp.buckets.flat.cpu().numpy()
+        if rank == 0:
+            q.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL exchange over xGMI (one-GPU boxes rehearse it over gloo)")
+def test_two_gpus_rccl_exchange_equals_single_rank(H):
+    """The N>1 path on REAL RCCL the moment a multi-GPU box runs the suite: two ranks on two GPUs, eager step with the
+    bucket all-reduces launched from gradient-ready hooks beside the two branch streams (fp32 and bf16 buckets), and the
+    captured step with the exchange after the replay -- each must equal the single-rank step on the concatenated batch."""
+    import torch.multiprocessing as mp
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(8, 48, 24, 128, 31)
+    y = (torch.rand(8, 4, generator=torch.Generator().manual_seed(5)) < 0.3).float()
+    dp = DataParallelStep(m, fusion_step_loss, bucket_bytes=256 << 10, overlap=False)
+    dp.set_global_batch(8)
+    dp.step(cu(h_a).bfloat16(), cu(h_t).bfloat16(), cu(m_a), cu(m_t), cu(y))
+    ref = dp.buckets.flat.cpu()
+    for name, flat in res.items():
+        got = torch.from_numpy(flat)
+        assert _rel(got, ref) < (1e-2 if "bf16" in name else 2e-3), (name, _rel(got, ref))
