@@ -274,9 +274,12 @@ def main():
             q = torch.randn(B * Lq, CFG["d_model"], device=device).bfloat16()
             k = torch.randn(B * Lk, CFG["d_model"], device=device).bfloat16()
             v = torch.randn(B * Lk, CFG["d_model"], device=device).bfloat16()
+            wb = _ops.attn_mask_bits()                # what the step itself does (hash replay unless HRIEMO_ATTN_MASK_BITS=1)
             o, lse, mbits = _ops.attn_fwd(q, k, v, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0, want_bits=True)
+            if not wb:
+                mbits = None
             do, dq, dk, dv = torch.randn_like(o), torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            tf = t_us(lambda: _ops.attn_fwd(q, k, v, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0, want_bits=True))
+            tf = t_us(lambda: _ops.attn_fwd(q, k, v, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0, want_bits=wb))
             tb = t_us(lambda: _ops.attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0, mask_bits=mbits))
             fl = 4.0 * B * Hh * Lq * Lk * hd
             roofl = min(PEAK_BF16_TFLOPS, Lq * Lk / (Lq + Lk) * 8.0)

@@ -151,7 +151,7 @@ __device__ __forceinline__ void tile_and_head(int ntiles, int nbh, int& tile, in
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int HD, int NW, int QW>
+template <int HD, int NW, int QW, bool WB>     // WB: also write the dropout keep-mask as bit words (AttnArgs::mbits)
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
@@ -293,9 +293,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
             const bool k0 = keep_lo(x, a.thr16), k1 = keep_hi(x, a.thr16);
             s[qs][n][2 * pr] = k0 ? s[qs][n][2 * pr] : 0.f;
             s[qs][n][2 * pr + 1] = k1 ? s[qs][n][2 * pr + 1] : 0.f;
-            bits |= (k0 ? 1u : 0u) << (n * 4 + 2 * pr) | (k1 ? 1u : 0u) << (n * 4 + 2 * pr + 1);
+            if (WB) bits |= (k0 ? 1u : 0u) << (n * 4 + 2 * pr) | (k1 ? 1u : 0u) << (n * 4 + 2 * pr + 1);
           }
-        if (a.mbits != nullptr && qbase + qs * 16 + i < a.Lq)       // this lane's 16 bits of the (query, key tile) word
+        if (WB && qbase + qs * 16 + i < a.Lq)       // this lane's 16 bits of the (query, key tile) word
           ((unsigned short*)(a.mbits + (((long)bh * a.Lq + qbase + qs * 16 + i) * nkt + kt)))[g] = (unsigned short)bits;
       }
     }
@@ -541,6 +541,189 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------ dK, dV (two-kernel path, hash mask)
+// The round-1 kernel, kept as it was tuned: the default backward (hash replay, dQ from its own kernel).  The kernel after it adds
+// the bit-word mask and the fused dQ; its different tile pipeline costs this one's register budget (3 blocks per CU at head_dim 96).
+template <int HD, int NW, int KW, int QT>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnArgs a) {
+  using G = AttnGeom<HD>;
+  constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
+  static_assert(QT == 32 || QT == 64, "query tile");
+  constexpr int NQS = QT / 16, NKQ = QT / 32;
+  // two LDS images of the (Q, dO, lse, delta) tile: the next tile is committed while the current one is consumed,
+  // so a query tile costs ONE barrier instead of two and the LDS stores overlap the MFMAs
+  constexpr int TILE_BYTES = 2 * QT * STRIDE + 2 * QT * 4;
+  __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  int tile, bh;
+  tile_and_head((a.Lk + NW * KW * 16 - 1) / (NW * KW * 16), a.B * a.H, tile, bh);
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int kbase = tile * (NW * KW * 16) + wave * KW * 16;
+
+  bf16x8 kreg[KW][KS], vreg[KW][KS];
+  bool kvalid[KW];
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) {
+    const int key = kbase + kw * 16 + i;
+    const int kc = min(key, a.Lk - 1);
+    kvalid[kw] = key < a.Lk && !(a.kpm != nullptr && a.kpm[(long)b * a.Lk + kc] != 0);
+    const bf16_t* kp = a.K + ((long)b * a.Lk + kc) * a.ldk + h * HD;
+    const bf16_t* vp = a.V + ((long)b * a.Lk + kc) * a.ldv + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      kreg[kw][ks] = (e < HD) ? *(const bf16x8*)(kp + e) : zero8();
+      vreg[kw][ks] = (e < HD) ? *(const bf16x8*)(vp + e) : zero8();
+    }
+  }
+  uint32_t hkb[KW];                     // hash base of this lane's key: key32 + (key>>1)*CB  (a-term added per query)
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) hkb[kw] = 0u;
+  f32x4 dk[KW][DT], dv[KW][DT];
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      dk[kw][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[kw][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  const float sl2 = a.scale * LOG2E;
+  const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) hkb[kw] = drop_base(key32, 0u, (uint32_t)((kbase + kw * 16 + i) >> 1));
+  const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
+  const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
+  const long lbase = ((long)b * a.H + h) * a.Lq;
+  const int nqt = (a.Lq + QT - 1) / QT;
+
+  const float l2ik = a.thr16 != 0 ? log2f(a.inv_keep) : 0.f, keepfrac = a.thr16 != 0 ? 1.f / a.inv_keep : 1.f;
+  constexpr bool PF = (NW == 4);
+  TileRegs<HD, QT, NT> qr, dor;
+  float lse_r = 0.f, del_r = 0.f;                 // lse / delta of query row `tid` of the tile in flight (tid < QT)
+  auto fetch = [&](int qt) {
+    tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, qt * QT, a.Lq, tid);
+    tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, qt * QT, a.Lq, tid);
+    if (tid < QT) {
+      const int q = qt * QT + tid;
+      lse_r = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
+      del_r = q < a.Lq ? a.delta[lbase + q] * keepfrac : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* base = lds + buf * TILE_BYTES;
+    tile_commit<HD, QT, NT>(qr, base, tid);
+    tile_commit<HD, QT, NT>(dor, base + QT * STRIDE, tid);
+    if (tid < QT) {
+      ((float*)(base + 2 * QT * STRIDE))[tid] = lse_r;
+      ((float*)(base + 2 * QT * STRIDE))[QT + tid] = del_r;
+    }
+  };
+  fetch(0);
+  commit(0);
+  if (nqt > 1) fetch(1);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const char* Qt = lds + (qt & 1) * TILE_BYTES;
+    const char* dOt = Qt + QT * STRIDE;
+    const float* lse_s = (const float*)(Qt + 2 * QT * STRIDE);
+    const float* del_s = lse_s + QT;
+    if (qt + 1 < nqt) {
+      commit((qt + 1) & 1);                       // image last read in iteration qt-1, released by its closing barrier
+      if (qt + 2 < nqt) fetch(qt + 2);
+    }
+
+    f32x4 s[KW][NQS], dp[KW][NQS];
+#pragma unroll
+    for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+      for (int qs = 0; qs < NQS; ++qs) {
+        s[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[kw][qs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int qs = 0; qs < NQS; ++qs)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 qfr = row_frag(Qt, STRIDE, qs * 16 + i, ks * 4 + g);
+        const bf16x8 dofr = row_frag(dOt, STRIDE, qs * 16 + i, ks * 4 + g);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          s[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kreg[kw][ks], s[kw][qs], 0, 0, 0);
+          dp[kw][qs] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vreg[kw][ks], dp[kw][qs], 0, 0, 0);
+        }
+      }
+    bf16x8 pf[KW][NKQ], dsf[KW][NKQ];
+#pragma unroll
+    for (int qs = 0; qs < NQS; ++qs) {
+      // lse_s holds (log2(1/(1-p_drop)) - lse*log2e), del_s holds delta*(1-p_drop): pk = p/(1-p_drop) straight
+      // from the exponent, P~ = keep ? pk : 0, dS = pk * (keep ? dP : 0  -  delta')
+      const f32x4 lse4 = *(LDS_PTR(const f32x4))(lse_s + qs * 16 + 4 * g);
+      const f32x4 del4 = *(LDS_PTR(const f32x4))(del_s + qs * 16 + 4 * g);
+#pragma unroll
+      for (int kw = 0; kw < KW; ++kw) {
+        const uint32_t key = (uint32_t)(kbase + kw * 16 + i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pk = kvalid[kw] ? EXP2(fmaf(s[kw][qs][r], sl2, lse4[r])) : 0.f;
+          float pd = pk, dpd = dp[kw][qs][r];
+          if (a.thr16 != 0) {
+            // the lane owns ONE key (pair index key>>1, half key&1) and walks the queries: a-term by addition
+            const uint32_t x = mix24(hkb[kw] + (uint32_t)(qt * QT + qs * 16 + 4 * g + r) * DROP_CA);
+            const bool keep = (key & 1u) ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16);
+            pd = keep ? pk : 0.f;
+            dpd = keep ? dpd : 0.f;
+          }
+          pf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)pd;
+          dsf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)(pk * (dpd - del4[r]));
+        }
+      }
+    }
+#pragma unroll
+    for (int kq = 0; kq < NKQ; ++kq)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8 dotf = tr_frag(dOt, STRIDE, 32 * kq, dt * 16, lane);
+        const bf16x8 qtf = tr_frag(Qt, STRIDE, 32 * kq, dt * 16, lane);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          dv[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf[kw][kq], dv[kw][dt], 0, 0, 0);
+          dk[kw][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[kw][kq], dk[kw][dt], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+  f32x4 csk[DT], csv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { csk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; csv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int kw = 0; kw < KW; ++kw) {
+    const int key = kbase + kw * 16 + i;
+    if (key >= a.Lk) continue;
+    bf16_t* dkp = a.dK + ((long)b * a.Lk + key) * a.lddk + h * HD + 4 * g;
+    bf16_t* dvp = a.dV + ((long)b * a.Lk + key) * a.lddv + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 wk, wv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float vk = dk[kw][dt][r] * a.scale, vv = dv[kw][dt][r];
+        wk[r] = (bf16_t)vk;
+        wv[r] = (bf16_t)vv;
+        csk[dt][r] += vk;                         // fp32 values before the bf16 rounding
+        csv[dt][r] += vv;
+      }
+      *(bf16x4*)(dkp + dt * 16) = wk;
+      *(bf16x4*)(dvp + dt * 16) = wv;
+    }
+  }
+  if (a.cskv != nullptr) {         // kernel-uniform
+    float* row = a.cskv + (long)(b * gridDim_tiles(a.Lk, NW * KW * 16) + tile) * (2L * a.H * HD) + h * HD;
+    __syncthreads();
+    block_colsum_store<DT, NW>(csk, (float*)lds, row, tid);
+    block_colsum_store<DT, NW>(csv, (float*)lds + NW * DT * 16, row + (long)a.H * HD, tid);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ dK, dV (+ dQ when fused)
 // One block = NW waves x KW 16-key sub-tiles = NK keys of one (batch, head), swept over all queries in tiles of QT rows.
 // Keys sit on the lanes (S = Q.K^T un-transposed), so P and dS are already the B operands of dV^T += dO^T.P and
@@ -555,7 +738,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED, bool PAIR = false>
 // two waves per SIMD are only requested where the kernel fits 256 registers WITHOUT spilling: co-resident blocks of the spilling
 // builds gave wrong dS elements on hardware (scripts_dev/dbg_attn.py; a single block per CU of the same code was exact)
-__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED)))) ? 2 : 1) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <= 96 && NW == 4 && KW == 1) ? 3 : ((PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED)))) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32, "query tile");
@@ -1029,19 +1212,24 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   // two 16-row query sub-tiles per wave (K/V fragment reuse) unless the key loop is short and the 128-row tiles pad the
   // query side visibly more than 64-row tiles do (L_q = 400, L_k = 128: 512 vs 448 rows, 44.3 vs 40.5 us)
   const bool short_keys_padded = Lk <= 128 && ((Lq + 63) / 64) * 64 * 20 < ((Lq + 127) / 128) * 128 * 19;
+  const bool wb = a.mbits != nullptr && a.thr16 != 0;
+#define FWD(HD, NW_, QW_, GRID, THREADS)                                                                         \
+  if (wb) hipLaunchKernelGGL((attn_fwd_kernel<HD, NW_, QW_, true>), dim3(GRID), dim3(THREADS), 0, st, a);         \
+  else hipLaunchKernelGGL((attn_fwd_kernel<HD, NW_, QW_, false>), dim3(GRID), dim3(THREADS), 0, st, a)
   if (Lq > 64 && attn_wide(0) && !short_keys_padded) {
-#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 2>), dim3(((Lq + 127) / 128) * B * H), dim3(256), 0, st, a)
+#define CALL(HD) FWD(HD, 4, 2, ((Lq + 127) / 128) * B * H, 256)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else if (Lq > 16) {
-#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 4, 1>), dim3(((Lq + 63) / 64) * B * H), dim3(256), 0, st, a)
+#define CALL(HD) FWD(HD, 4, 1, ((Lq + 63) / 64) * B * H, 256)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_fwd_kernel<HD, 1, 1>), dim3(B * H), dim3(64), 0, st, a)
+#define CALL(HD) FWD(HD, 1, 1, B * H, 64)
     DISPATCH_HD(head_dim, CALL)
 #undef CALL
   }
+#undef FWD
   HRIEMO_LAUNCH_CHECK("attn_fwd_kernel");
   hriemo_prof_end(HP_ATTN_FWD, st, 4.0 * B * H * (double)Lq * Lk * head_dim);
   return 0;
@@ -1208,7 +1396,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32, false, false>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_hash_kernel<HD, 4, 2, 32>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     }
@@ -1218,7 +1406,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, 32, false, false>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_hash_kernel<HD, 4, 1, 32>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     }
@@ -1228,7 +1416,7 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     } else {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32, false, false>), dim3(B * H), dim3(64), 0, st, a)
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_hash_kernel<HD, 1, 1, 32>), dim3(B * H), dim3(64), 0, st, a)
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     }
