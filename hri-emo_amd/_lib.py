@@ -20,6 +20,7 @@ _SIGS = {
     "hriemo_attn_fwd": ("plplplplppiiiiifQpIipp", "i"),
     "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIipppp", "i"),
     "hriemo_attn_mask_bytes": ("iiii", "l"),
+    "hriemo_attn_bwd_single_pass": ("iiii", "i"),
     "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),
     "hriemo_attn_bwd_dq_colsum_rows": ("iiiii", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),

@@ -431,17 +431,20 @@ def _in_backward():
 
 # Dropout keep-mask as bit words from the forward to the backward (include/hriemo.h, drop_mask_bits).  Measured at cfg 2: in the
 # two-kernel backward the bit words save the hash but cost three registers in the dK/dV kernel (a wave per SIMD at head_dim 96)
-# and a 2-byte store per lane and key tile in the forward -- no gain (profiles/r02_attention.log); they pay in the single-pass
-# backward, which is off by default (HRIEMO_ATTN_FUSED_BWD).  So the product path replays the hash unless this is switched on.
-ATTN_MASK_BITS = _os_env_bits = None
+# and a 2-byte store per lane and key tile in the forward -- no gain; in the single-pass backward (16 < L_k <= 128) they pay
+# (profiles/r02_attention.log).  So a site asks for them exactly when its backward is the single kernel; HRIEMO_ATTN_MASK_BITS=1 / 0
+# forces them on / off everywhere.
+ATTN_MASK_BITS = None
 
 
-def attn_mask_bits():
+def attn_mask_bits(B, H, Lk, hd):
     global ATTN_MASK_BITS
     if ATTN_MASK_BITS is None:
         import os
-        ATTN_MASK_BITS = os.environ.get("HRIEMO_ATTN_MASK_BITS", os.environ.get("HRIEMO_ATTN_FUSED_BWD", "0")) == "1"
-    return ATTN_MASK_BITS
+        ATTN_MASK_BITS = os.environ.get("HRIEMO_ATTN_MASK_BITS", "auto")
+    if ATTN_MASK_BITS in ("0", "1"):
+        return ATTN_MASK_BITS == "1"
+    return bool(_lib.lib().hriemo_attn_bwd_single_pass(B, H, Lk, hd))
 
 
 def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=False):
@@ -658,7 +661,7 @@ class SelfAttnLN(torch.autograd.Function):
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         qkv = proj_fwd(Operand(x2, mx_of(x)), sh, w_in, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        o, lse, mbits = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off, want_bits=True) if attn_mask_bits() else \
+        o, lse, mbits = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off, want_bits=True) if attn_mask_bits(B, H, L, hd) else \
             attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN,
@@ -719,7 +722,7 @@ class CrossAttnLN(torch.autograd.Function):
         q = proj_fwd(Operand(xq2, mx_of(xq)), sh, w_in, w_in16, b_in, rows=(0, d))
         kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
-        o, lse, mbits = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=True) if attn_mask_bits() else \
+        o, lse, mbits = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=True) if attn_mask_bits(B, H, Lk, hd) else \
             attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN,

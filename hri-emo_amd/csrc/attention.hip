@@ -958,7 +958,15 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
             pd = keep ? pk : 0.f;
             dpd = keep ? dpd : 0.f;
           }
-          const float dsv = pk * (dpd - del4[r]);
+          // The subtraction is pinned to a scalar v_sub_f32: left to the compiler, the two key sub-tiles' (dP - delta') pairs
+          // of the BITS + FUSED variants become  v_pk_add_f32 d, a, b op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]  (both halves minus
+          // the high dword of the (lse', delta') pair), and with two waves per SIMD that build sporadically (~1e-5 of the
+          // elements, always the high half in lanes 48..63) produced dS = pk * dP, the subtraction lost -- measured with
+          // scripts_dev/dbg_attn.py; the instruction alone does not misbehave (scripts_dev/pkadd_probe.hip), the cause inside
+          // this instruction mix is not understood.  The scalar form is exact on the same tests.
+          float dif;
+          asm("v_sub_f32 %0, %1, %2" : "=v"(dif) : "v"(dpd), "v"(del4[r]));
+          const float dsv = pk * dif;
           if (FUSED) dsum[kw] += dsv;
           pf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)pd;
           dsf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)dsv;
@@ -1259,17 +1267,19 @@ static bool bwd_wide(int L, int BH, int head_dim) {
   return en < 0.75 && ew >= 0.9;
 }
 // Single-pass backward: one block holds all keys of a (batch, head) (16 < L_k <= 128) and produces dQ, dK and dV together
-// (5 GEMMs per tile instead of 7, Q/K/V/dO read once): a2t backward 63 us instead of 105 at cfg 2.
-// OFF by default (HRIEMO_ATTN_FUSED_BWD=1 turns it on): with the bit-word mask and two waves per SIMD it returned a few
-// wrong dS elements per launch on hardware (P~, delta and the masks themselves exact; the hash-mask build and every build at
-// one wave per SIMD exact; two workgroups per CU or one paired workgroup alike; with or without spills; cause not found --
-// scripts_dev/dbg_attn.py).  A kernel that is only right when nothing shares its SIMD does not ship.
+// (5 GEMMs per tile instead of 7, Q/K/V/dO read once): a2t backward 82 us instead of 114 at cfg 2.
+// ON by default (HRIEMO_ATTN_FUSED_BWD=0 selects the two-kernel path).  Its first build returned a few wrong dS elements per
+// launch with the bit-word mask at two waves per SIMD; traced (scripts_dev/dbg_attn.py) to the compiler's packed form of the
+// (dP - delta') subtraction, pinned to v_sub_f32 in the kernel since; 4.4e9 elements bit-identical between the bit-word and the
+// hash variant afterwards (scripts_dev/soak_attn.py, profiles/r02_attn_soak.log).
 static bool bwd_fused(int Lk, int head_dim, int BH) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '1') ? 1 : 0; }
+  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
   // (an odd number of (batch, head) problems cannot be paired: two-kernel path)
   return on && Lk > 16 && Lk <= 128 && head_dim >= 32 && (BH % 2 == 0 || (head_dim == 128 && Lk > 64));
 }
+
+extern "C" int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim) { return bwd_fused(Lk, head_dim, B * H) ? 1 : 0; }
 
 // rows of the column-sum partials hriemo_attn_bwd leaves behind: dK|dV side (sequence of length Lk) ...
 extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {

@@ -82,8 +82,12 @@ int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void
 /* drop_mask_bits (optional, hriemo_attn_mask_bytes(B,H,Lq,Lk) bytes, 8-byte aligned): the dropout keep-mask as bits, one
  * 64-bit word per (batch, head, query, 64-key tile), written by hriemo_attn_fwd when p_drop > 0 and read by hriemo_attn_bwd
  * instead of replaying the hash (NULL on either side: the hash is replayed; both give the same mask).
- * For 16 < Lk <= 128 hriemo_attn_bwd is ONE kernel (dQ, dK, dV together; `delta` is then not written). */
+ * For 16 < Lk <= 128 hriemo_attn_bwd is ONE kernel (dQ, dK, dV together; HRIEMO_ATTN_FUSED_BWD=0 in the environment selects
+ * the two-kernel path). */
 long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk);
+/* 1 when hriemo_attn_bwd runs as the single kernel for this problem (the bit words pay there; the two-kernel path is as fast
+ * replaying the hash) -- what the host side asks before it requests drop_mask_bits from the forward */
+int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim);
 /* Optional by-product of hriemo_attn_bwd (either pointer may be NULL): per-block column sums of the dQ tiles,
  * [hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, head_dim), H*head_dim] fp32, and of the dK | dV tiles,
  * [hriemo_attn_bwd_colsum_rows(B, H, Lk, head_dim), 2*H*head_dim] fp32 (values before their bf16 rounding).  Summed over rows
