@@ -418,17 +418,31 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
   leave();
 }
 
-// out[m][n] (+)= sum_s ws[s][m][n]
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M, int N,
-                                     int splitk, int accumulate) {
-  const long nv = (long)M * N / 4;
+// out[m][n] (+)= sum_s ws[s][m][n], slabs summed in slice order (bit-identical from run to run).  Four slabs' loads are in
+// flight per lane before the first add (the k-loop is latency-bound otherwise: 0.5 TB/s measured on the 66 MB of a
+// 3072x768x7 reduction in round 1's form, profiles/r02_bench_kernel_stats.csv).
+// (Tried in round 2: no separate launch at all -- the wave that stores the last slab of its 64-column sub-tile reduces it,
+// arrival counters in device memory.  The slabs come from other XCDs, so the hand-over needs agent-scope release/acquire
+// fences, i.e. an L2 write-back and invalidate per wave: 156 us instead of 56 for the 768x768x25600 weight gradient.  Dropped.)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M, int N,
+                                                            int splitk, int accumulate) {
+  const long nv = (long)M * N / 4, slab = (long)M * N;
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
     const long e = v * 4;
     const int m = (int)(e / N), n = (int)(e - (long)m * N);
-    f32x4 s = *(const f32x4*)(ws + e);
-    for (int k = 1; k < splitk; ++k) s += *(const f32x4*)(ws + (long)k * M * N + e);
+    const float* src = ws + e;
     float* dst = C + (long)m * ldc + n;
-    if (accumulate) s += *(const f32x4*)dst;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) c = *(const f32x4*)dst;
+    f32x4 s = *(const f32x4*)src;
+    int k = 1;
+    for (; k + 4 <= splitk; k += 4) {
+      const f32x4 a0 = *(const f32x4*)(src + (k + 0) * slab), a1 = *(const f32x4*)(src + (k + 1) * slab);
+      const f32x4 a2 = *(const f32x4*)(src + (k + 2) * slab), a3 = *(const f32x4*)(src + (k + 3) * slab);
+      s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < splitk; ++k) s += *(const f32x4*)(src + k * slab);
+    if (accumulate) s += c;
     *(f32x4*)dst = s;
   }
 }
@@ -590,7 +604,7 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   if (splitk > 1) {
     const long nv = (long)M * N / 4;
     int grid = (int)((nv + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    if (grid > 16 * hriemo_num_cus()) grid = 16 * hriemo_num_cus();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, workspace, (float*)C, ldc, M, N, splitk,
                        accumulate);
     HRIEMO_LAUNCH_CHECK("splitk_reduce_kernel");

@@ -72,6 +72,36 @@ def test_gemm_tn_exact_splitk(ops, M, N, K):
     assert torch.equal(big[8:].cpu(), ref) and float(big[:8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(25600, 768, 768), (8192, 3072, 768), (25600, 768, 2304)])
+def test_gemm_tn_splitk_weight_gradient_shapes(ops, M, N, K):
+    """Weight-gradient shapes of cfg 2 (split-K slabs + reduce): exact on integers, with accumulate, repeated on the same stream
+    and interleaved with a second stream (private workspaces); bit-identical from run to run on random data (fixed summation
+    order of the slabs)."""
+    dY, X = ints((M, N), -2, 3, seed=21), ints((M, K), -2, 3, seed=22)
+    dYd, Xd = dY.cuda().bfloat16(), X.cuda().bfloat16()
+    ref = dY.t().double() @ X.double()
+    out = torch.zeros((N, K), dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    out2 = torch.zeros((N, K), dtype=torch.float32, device="cuda")
+    for rep in range(3):
+        ops.linear_dw(dYd, Xd, out, accumulate=True)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.linear_dw(dYd, Xd, out2, accumulate=True)
+        torch.cuda.current_stream().wait_stream(side)
+        assert torch.equal(out.double().cpu(), (rep + 1) * ref), rep
+        assert torch.equal(out2.double().cpu(), (rep + 1) * ref), rep
+    g = torch.Generator().manual_seed(5)
+    A, B_ = torch.randn(M, N, generator=g).cuda().bfloat16(), torch.randn(M, K, generator=g).cuda().bfloat16()
+    r1 = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    r2 = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    ops.linear_dw(A, B_, r1)
+    ops.linear_dw(A, B_, r2)
+    assert torch.equal(r1, r2)
+    want = A.float().t() @ B_.float()
+    assert float((r1 - want).abs().max()) <= 2e-3 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_gemm_every_tile_config_and_persistent_walk(ops, cfg):
     """Each tile configuration forced in turn: ragged edges, every epilogue, and a problem with more tiles than
