@@ -23,6 +23,14 @@ _SIGS = {
     "hriemo_attn_bwd_single_pass": ("iiii", "i"),
     "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),
     "hriemo_attn_bwd_dq_colsum_rows": ("iiiii", "i"),
+    "hriemo_split_bf16x3": ("pliipiip", "i"),
+    "hriemo_attn_fwd_f32": ("plplplplppiiiiip", "i"),
+    "hriemo_attn_probs_f32": ("plplpppiiiiip", "i"),
+    "hriemo_add_ln_f32": ("ppppppiifp", "i"),
+    "hriemo_masked_mean_f32": ("pppiiip", "i"),
+    "hriemo_gate_input_f32": ("pppiip", "i"),
+    "hriemo_sigmoid_beta_f32": ("pppiip", "i"),
+    "hriemo_fuse_f32": ("ppipippiiip", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
     "hriemo_add_ln_fwd_mx8": ("pppppppppiiffQpIlpplp", "i"),

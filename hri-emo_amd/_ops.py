@@ -316,6 +316,34 @@ def gemm_mode():
     return GEMM_MODE
 
 
+# ---- arithmetic of the whole path: 'bf16' (product path: bf16 GEMM operands, fp32 accumulate, fp32 residual twins) or 'fp32'
+# (inference only, hri-emo_amd/_fp32.py: the reference's fp32 arithmetic to 1e-3).  HRIEMO_PRECISION at first use, set_precision().
+PRECISION = None
+
+
+def set_precision(mode):
+    global PRECISION
+    if mode not in ("bf16", "fp32"):
+        raise ValueError(f"set_precision: {mode!r} (expected 'bf16' or 'fp32')")
+    PRECISION = mode
+
+
+def precision():
+    global PRECISION
+    if PRECISION is None:
+        import os
+        mode = os.environ.get("HRIEMO_PRECISION", "bf16")
+        if mode not in ("bf16", "fp32"):
+            raise ValueError(f"HRIEMO_PRECISION={mode!r} (expected 'bf16' or 'fp32')")
+        PRECISION = mode
+    return PRECISION
+
+
+def _fp32():
+    from . import _fp32 as m
+    return m
+
+
 MX_MIN_ROWS = 1024     # below this a GEMM is latency-bound (decoder queries, gate MLP): fp8 operands buy nothing there
 
 
@@ -649,6 +677,9 @@ class SelfAttnLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        if precision() == "fp32":
+            _fp32().guard(ctx, "self-attention sub-layer")
+            return _fp32().self_attn_ln(x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w)
         _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
@@ -708,6 +739,9 @@ class CrossAttnLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+        if precision() == "fp32":
+            _fp32().guard(ctx, "cross-attention sub-layer")
+            return _fp32().cross_attn_ln(xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w)
         _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(xq)
@@ -773,6 +807,9 @@ class FFNLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off):
+        if precision() == "fp32":
+            _fp32().guard(ctx, "feed-forward sub-layer")
+            return _fp32().ffn_ln(x, x32, w1, b1, w2, b2, gamma, beta, sh)
         _require_fp32_masters(w1, b1, w2, b2, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
@@ -830,6 +867,9 @@ class BetaGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t):
+        if precision() == "fp32":
+            _fp32().guard(ctx, "BetaGate")
+            return _fp32().beta_gate(h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t)
         _require_fp32_masters(ga, ba, gt, bt, w1, b1, w2, b2)
         _require_gpu(h_a)
         h_a32, h_t32 = _c32(h_a32), _c32(h_t32)
@@ -919,6 +959,9 @@ class LegacyBetaGateFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h_a, h_t, w1, b1, w2, b2, sh, kpm_a, kpm_t):
+        if precision() == "fp32":
+            raise NotImplementedError("HRIEMO_PRECISION=fp32 covers the tacfn model family (FusionWithEmotionDecoder); the legacy "
+                                      "scalar gate (models/beta_gate.py) runs on the bf16 path only")
         _require_fp32_masters(w1, b1, w2, b2)
         _require_gpu(h_a)
         B, La, d = h_a.shape
@@ -1030,6 +1073,9 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, sh):
+        if precision() == "fp32":
+            _fp32().guard(ctx, "Linear projection")
+            return _fp32().linear_any_k(x, w, b, sh)
         _require_fp32_masters(w, b)
         _require_gpu(x)
         K = x.shape[-1]

@@ -22,6 +22,13 @@ class BetaGate(nn.Module):
         B, La, _ = a.shape
         Lt = t.shape[1]
         kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
+        if _ops.precision() == "fp32":
+            # called directly (not through Function.apply): h_fusion carries its fp32 twin as an attribute to the decoder
+            from hri_emo_amd import _fp32
+            if torch.is_grad_enabled() and (a.requires_grad or any(p.requires_grad for p in self.parameters())):
+                raise RuntimeError("BetaGate: HRIEMO_PRECISION=fp32 is an inference mode (forward only) -- run it under torch.no_grad()")
+            return _fp32.beta_gate(a, a32, t, t32, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight, self.norm_t.bias,
+                                   self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, self._sh, kpm_a, kpm_t)
         return _ops.BetaGateFn.apply(a, a32, t, t32, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight,
                                      self.norm_t.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
                                      self.mlp[2].bias, self._sh, kpm_a, kpm_t)
@@ -31,4 +38,7 @@ class BetaGate(nn.Module):
         a, a32 = _ops.as_pair(h_a)
         t, t32 = _ops.as_pair(h_t)
         h_fusion, beta = self._fwd_pair(a, a32, t, t32, mask_a, mask_t)
+        if _ops.precision() == "fp32" and out_dtype != torch.bfloat16:
+            from hri_emo_amd import _fp32
+            return _fp32.f32_of(h_fusion).to(out_dtype), beta
         return h_fusion.to(out_dtype), beta

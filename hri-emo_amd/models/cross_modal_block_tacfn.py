@@ -60,15 +60,18 @@ class CrossModalBlock(nn.Module):
         seed = _ops.next_seed(self.training and p > 0)
         s = self._site
         _ops._require_gpu(a)
+        # fp32 inference mode: the key/value side of a cross-attention reads the fp32 twin of the other branch, not its bf16 copy
+        fp32 = _ops.precision() == "fp32"
+        kv = lambda x16, x32: x32 if (fp32 and x32 is not None) else x16          # noqa: E731
         main = torch.cuda.current_stream(a.device)
         _ops.note_main_stream(main)
         side = _ops.side_stream(a.device)
         if side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
             t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
-            x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
-            x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
+            x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
             t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
         else:
             # The audio and text branches only meet at the two cross-attentions (each reads the OTHER branch's
@@ -86,10 +89,13 @@ class CrossModalBlock(nn.Module):
             side.wait_stream(main)
             _ops.share(t_s, main)
             _ops.share(a_s, side)
+            if fp32:
+                _ops.share(t_s32, main)
+                _ops.share(a_s32, side)
             with torch.cuda.stream(side):
-                x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)
+                x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)
                 t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])
-            x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])
             main.wait_stream(side)
             for x_ in (t_cm, t_cm32, w_t, w_t2a):

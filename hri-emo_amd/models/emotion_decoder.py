@@ -8,6 +8,15 @@ except ImportError:            # imported as top-level `models` (PYTHONPATH=<rep
     from hri_emo_amd import _ops
 
 
+def _memory16(memory):
+    """bf16 GEMM operand of the encoder memory; in the fp32 inference mode it carries the caller's fp32 values along"""
+    m16 = _ops.to_bf16(memory)
+    if _ops.precision() == "fp32" and memory.dtype != torch.bfloat16:
+        from hri_emo_amd import _fp32
+        m16 = _fp32.tag32(m16, memory.float())
+    return m16
+
+
 class ExplainableDecoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
         super().__init__()
@@ -49,7 +58,11 @@ class ExplainableDecoderLayer(nn.Module):
     def forward(self, tgt, memory, memory_key_padding_mask=None, return_attention=False):
         out_dtype = tgt.dtype
         t16, t32 = _ops.as_pair(tgt)
-        t16, t32, w = self._fwd_pair(t16, t32, _ops.to_bf16(memory), memory_key_padding_mask, bool(return_attention))
+        mem = _memory16(memory)
+        if _ops.precision() == "fp32":
+            from hri_emo_amd import _fp32
+            mem = _fp32.f32_of(mem)
+        t16, t32, w = self._fwd_pair(t16, t32, mem, memory_key_padding_mask, bool(return_attention))
         tgt = _ops.from_pair(t16, t32, out_dtype)
         return (tgt, w) if return_attention else (tgt, None)
 
@@ -74,6 +87,9 @@ class EmotionDecoder(nn.Module):
             # fp8 GEMM mode: every layer projects the same memory to K | V -- quantise it once
             m2 = memory16 if memory16.is_contiguous() else memory16.contiguous()
             memory16 = _ops.tag_mx(m2, _ops.quant_mx8(m2.view(-1, m2.shape[2])))
+        if _ops.precision() == "fp32":
+            from hri_emo_amd import _fp32
+            memory16 = _fp32.f32_of(memory16)          # the layers read the fp32 values of the memory (h_fusion's twin)
         for layer in self.layers:
             out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need)
             if need and attn_map is not None:
@@ -85,7 +101,7 @@ class EmotionDecoder(nn.Module):
         return z, logits, all_layers_attn
 
     def forward(self, memory, memory_key_padding_mask=None, return_attention=False):
-        z, logits, maps = self._fwd(_ops.to_bf16(memory), memory_key_padding_mask, bool(return_attention), memory.dtype)
+        z, logits, maps = self._fwd(_memory16(memory), memory_key_padding_mask, bool(return_attention), memory.dtype)
         if return_attention:
             return z, logits, maps
         return z, logits

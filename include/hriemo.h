@@ -201,6 +201,32 @@ int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const f
                        const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
                        float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hriemo_stream_t stream);
 
+/* ---- fp32-tolerance inference mode (csrc/fp32mode.hip; host side hri-emo_amd/_fp32.py, HRIEMO_PRECISION=fp32).
+ * The reference's modules are fp32 nn.Modules throughout (models/cross_modal_block_tacfn.py:70-125, beta_gate_tacfn.py:68-118,
+ * emotion_decoder.py:30-64,116-162); this mode reproduces them to 1e-3 (forward only, no dropout):
+ *  - hriemo_split_bf16x3: X fp32 [M,K] (row stride ldx) -> Y bf16 [M,3K], x = hi + mid + ..: layout 0 (activations) [hi|mid|hi],
+ *    layout 1 (weights) [hi|hi|mid]; relu != 0 applies max(x,0) first.  hriemo_gemm_bf16 over the 3K-long contraction with fp32
+ *    output then gives hi.hi + mid.hi + hi.mid, the fp32 product to 2^-16 relative (nn.Linear, nn.MultiheadAttention in/out-proj);
+ *  - hriemo_attn_fwd_f32 / hriemo_attn_probs_f32: softmax(Q K^T / sqrt(hd) + key padding) V on the fp32 MFMA
+ *    (v_mfma_f32_16x16x4_f32), operands and outputs fp32 with row strides; lse = log-sum-exp of the scaled scores per
+ *    (batch, head, query), probs = head-averaged probabilities [B,Lq,Lk] (need_weights=True);
+ *  - hriemo_add_ln_f32: Y32 (and the bf16 copy Y16 when non-NULL) = LayerNorm(G + X) (X may be NULL), fp32 in and out;
+ *  - gate pieces of models/beta_gate_tacfn.py in fp32: masked mean (:6-24), gate input [a,t,|a-t|,a*t] (:87-89),
+ *    w = sigmoid(pre) / beta = mean(w) (:92-95), h = w*a + (1-w)*t over the first L positions (:98-116; A, T are [B,La,d], [B,Lt,d]). */
+int hriemo_split_bf16x3(const float* X, long ldx, int M, int K, void* Y, int layout, int relu, hriemo_stream_t stream);
+int hriemo_attn_fwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, float* O, long ldo,
+                        const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
+                        hriemo_stream_t stream);
+int hriemo_attn_probs_f32(const float* Q, long ldq, const float* K, long ldk, const unsigned char* key_padding_mask,
+                          const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, hriemo_stream_t stream);
+int hriemo_add_ln_f32(const float* G, const float* X, const float* gamma, const float* beta, float* Y32, void* Y16, int M, int d,
+                      float eps, hriemo_stream_t stream);
+int hriemo_masked_mean_f32(const float* X, const unsigned char* mask, float* pooled, int B, int L, int d, hriemo_stream_t stream);
+int hriemo_gate_input_f32(const float* a_pool, const float* t_pool, float* gate_in, int B, int d, hriemo_stream_t stream);
+int hriemo_sigmoid_beta_f32(const float* pre, float* w, float* beta, int B, int d, hriemo_stream_t stream);
+int hriemo_fuse_f32(const float* w, const float* A, int La, const float* T, int Lt, float* H32, void* H16, int B, int L, int d,
+                    hriemo_stream_t stream);
+
 /* ---- per-kernel-class HIP-event timing on the launch stream (bench.py roofline leg) */
 int hriemo_prof_enable(int on);
 int hriemo_prof_nclass(void);
