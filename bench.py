@@ -210,8 +210,8 @@ def main():
     log(f"{ms:.3f} ms/step -> {value:.1f} utt/s (host enqueue {host_ms:.3f} ms/step)")
 
     # secondary number: the same step with ragged key-padding masks, valid length ~U[0.5 L, L] per sample and
-    # modality.  PAD keys are masked, PAD query rows are still computed (as in the reference), so this mainly shows that
-    # masks cost nothing; hri_emo_amd.data.trim_padding / length_bucketed_batches are what remove the padding itself.
+    # modality.  PAD keys are masked, PAD query rows are still computed (as in the reference), so the first number mainly shows
+    # that masks cost nothing; the second is the packed (varlen) encoder, which computes the valid rows only.
     ragged = None
     if rank == 0 and world == 1 and not a.no_roofline:
         g = torch.Generator().manual_seed(4321)
@@ -228,6 +228,27 @@ def main():
         rms = (time.perf_counter() - t1) / 10 * 1e3
         ragged = {"ms_per_step": round(rms, 3), "value": round(B / (rms * 1e-3), 1), "valid_fraction": round(float((la.sum() / T_A + lt.sum() / T_T) / (2 * B)), 3)}
         log(f"ragged masks: {rms:.3f} ms/step")
+        # the same ragged batch through the packed (varlen) encoder, SURVEY 8(f) rank 4: rows of PAD positions are not computed.
+        # Its graph bakes this batch's lengths in, so it is captured for this leg and the headline capture restored afterwards.
+        if not a.no_graph:
+            import hri_emo_amd as _H
+            _H.set_varlen(True)
+            try:
+                dp.capture(*rb)
+                for _ in range(3):
+                    dp.step(*rb)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    dp.step(*rb)
+                torch.cuda.synchronize()
+                pms = (time.perf_counter() - t1) / 10 * 1e3
+                ragged["packed_ms_per_step"] = round(pms, 3)
+                ragged["packed_value"] = round(B / (pms * 1e-3), 1)
+                log(f"ragged masks, packed (varlen) encoder: {pms:.3f} ms/step")
+            finally:
+                _H.set_varlen(False)
+            dp.capture(*batch)
         dp.step(*batch)                              # gradients of the headline batch again for the legs below
 
     # optimizer step, timed separately: the trainer's clip_grad_norm_(5.0) + AdamW(lr 1e-4, wd 1e-2) on the

@@ -12,7 +12,7 @@ from .models.fusion_with_emotion_decoder import FusionWithEmotionDecoder  # noqa
 from .models.mosei_fusion_with_emotion_decoder import MoseiFusionWithEmotionDecoder  # noqa: F401
 from .models.fusion_classifier import FusionClassifier  # noqa: F401
 
-from ._ops import set_gemm_mode, gemm_mode, enable_fused_wgrad, set_precision, precision  # noqa: F401
+from ._ops import set_gemm_mode, gemm_mode, enable_fused_wgrad, set_precision, precision, set_varlen, varlen  # noqa: F401
 
-__all__ = ["set_gemm_mode", "gemm_mode", "enable_fused_wgrad", "set_precision", "precision", "CrossModalBlock", "CrossModalTransformer", "BetaGate", "EmotionDecoder", "ExplainableDecoderLayer",
+__all__ = ["set_gemm_mode", "gemm_mode", "enable_fused_wgrad", "set_precision", "precision", "set_varlen", "varlen", "CrossModalBlock", "CrossModalTransformer", "BetaGate", "EmotionDecoder", "ExplainableDecoderLayer",
            "FusionWithEmotionDecoder", "MoseiFusionWithEmotionDecoder", "FusionClassifier"]

@@ -19,6 +19,8 @@ _SIGS = {
     "hriemo_gemm_mx8_force_config": ("i", "i"),
     "hriemo_attn_fwd": ("plplplplppiiiiifQpIipp", "i"),
     "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIipppp", "i"),
+    "hriemo_attn_fwd_varlen": ("plplplplpppiiiiifQpIipp", "i"),
+    "hriemo_attn_bwd_varlen": ("plplplplplplplplppppiiiiifQpIipppp", "i"),
     "hriemo_attn_mask_bytes": ("iiii", "l"),
     "hriemo_attn_bwd_single_pass": ("iiii", "i"),
     "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),

@@ -112,8 +112,14 @@ def branch_streams(device):
 
 def share(t, stream):
     """tensor produced on another stream is about to be read on `stream`"""
-    if t is not None:
+    if isinstance(t, torch.Tensor):
         t.record_stream(stream)
+    elif isinstance(t, tuple):
+        for e in t:
+            share(e, stream)
+    elif t is not None and hasattr(t, "cu"):             # Seq (packed sequences): its index tensors
+        t.cu.record_stream(stream)
+        t.idx.record_stream(stream)
     return t
 
 
@@ -475,19 +481,27 @@ def attn_mask_bits(B, H, Lk, hd):
     return bool(_lib.lib().hriemo_attn_bwd_single_pass(B, H, Lk, hd))
 
 
-def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=False):
-    """-> (o, lse) or, with want_bits, (o, lse, mask_bits|None): the dropout keep-mask as bit words for the backward"""
-    o = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
+def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=False, cu=None):
+    """-> (o, lse) or, with want_bits, (o, lse, mask_bits|None): the dropout keep-mask as bit words for the backward.
+    cu = (cu_seqlens_q, cu_seqlens_k) int32 device tensors: q / k / v hold packed rows, Lq / Lk are the longest sequences"""
+    o = torch.empty((q.shape[0], H * hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
     mb = None
     if want_bits and p > 0:
         mb = torch.empty(_lib.lib().hriemo_attn_mask_bytes(B, H, Lq, Lk) // 8, dtype=torch.int64, device=q.device)
-    _lib.call("hriemo_attn_fwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-              _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _p(mb), _stream())
+    if cu is not None:
+        if kpm is not None:
+            raise ValueError("attn_fwd: packed sequences carry their lengths; no key_padding_mask")
+        _lib.call("hriemo_attn_fwd_varlen", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                  _p(cu[0]), _p(cu[1]), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _p(mb),
+                  _stream())
+    else:
+        _lib.call("hriemo_attn_fwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                  _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _p(mb), _stream())
     return (o, lse, mb) if want_bits else (o, lse)
 
 
-def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None, mask_bits=None):
+def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None, mask_bits=None, cu=None):
     """bias_grad = (db_q [d], db_kv [2d]) fp32 views the column sums of dQ and dK|dV go to: the kernels leave per-block partial
     sums behind (fp32 values before the bf16 rounding of dQ/dK/dV); inside backward with the fused path they are finished by the
     launch-boundary reduce (accumulating), otherwise by one reduce launch right here (overwriting).  Returns True if it took
@@ -500,10 +514,16 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
         rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
         pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
         pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
-    _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
-              _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
-              _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
-              _p(pq), _p(pkv), _p(mask_bits), _stream())
+    if cu is not None:
+        _lib.call("hriemo_attn_bwd_varlen", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                  _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(cu[0]), _p(cu[1]),
+                  _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
+                  _p(pq), _p(pkv), _p(mask_bits), _stream())
+    else:
+        _lib.call("hriemo_attn_bwd", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                  _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
+                  _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
+                  _p(pq), _p(pkv), _p(mask_bits), _stream())
     if fold:
         d = H * hd
         deferred = bias_grad[2] if len(bias_grad) > 2 else False
@@ -671,6 +691,83 @@ def _contig_bf16(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ----------------------------------------------------------------------------- packed (varlen) sequences, SURVEY 8(f) rank 4
+# The reference pads every sample to the batch maximum and computes the PAD rows too (train_fusion_seq_level_decoder.py:191-232).
+# Opt-in (HRIEMO_VARLEN=1 / set_varlen(True)): the cross-modal encoder -- 9/10 of the FLOPs -- runs on the VALID rows only: the
+# row-wise kernels (GEMM, LayerNorm, FFN) see [N_valid, d] matrices, the attention kernels take cu_seqlens
+# (hriemo_attn_*_varlen); the rows are scattered back to the padded layout before the gate, whose pooling, fusion and the
+# decoder's masks only ever read valid positions -- so logits, beta and z are those of the padded path.  The packing needs the
+# lengths on the host (one sync per distinct mask tensor); a step captured into a hipGraph bakes them in and may only be
+# replayed with the same masks (dp.DataParallelStep checks).
+VARLEN = None
+
+
+def set_varlen(on):
+    global VARLEN
+    VARLEN = bool(on)
+
+
+def varlen():
+    global VARLEN
+    if VARLEN is None:
+        VARLEN = _os.environ.get("HRIEMO_VARLEN", "0") == "1"
+    return VARLEN
+
+
+class Seq:
+    """packed rows of one modality: cu int32 [B+1] (device), idx int64 [N] packed row -> row of the padded [B*L] layout"""
+    __slots__ = ("cu", "idx", "B", "L", "Lmax", "N")
+
+    def __init__(self, cu, idx, B, L, Lmax, N):
+        self.cu, self.idx, self.B, self.L, self.Lmax, self.N = cu, idx, B, L, Lmax, N
+
+
+_SEQ_PLANS = {}
+
+
+def seq_plan(mask, B, L):
+    """Seq for a [B, L] padding mask (True = PAD) whose valid positions are a prefix of every row with at least one valid
+    position (what the collate produces); None when the mask does not have that form (the padded path then runs)."""
+    if mask is None:
+        return None
+    key = (mask.data_ptr(), tuple(mask.shape), mask._version, str(mask.device))
+    hit = _SEQ_PLANS.get(key)
+    if hit is not None:
+        return hit[0]
+    if CAPTURING:
+        raise RuntimeError("varlen: the sequence lengths must be known before the step is captured (run one eager step first)")
+    valid = ~mask.bool()
+    lens = valid.sum(1)
+    prefix = bool((valid == (torch.arange(L, device=mask.device)[None, :] < lens[:, None])).all()) and bool((lens > 0).all())
+    plan = None
+    if prefix:
+        cu = torch.zeros(B + 1, dtype=torch.int32, device=mask.device)
+        cu[1:] = torch.cumsum(lens, 0)
+        idx = valid.reshape(-1).nonzero().reshape(-1)
+        plan = Seq(cu, idx, B, L, int(lens.max()), int(idx.numel()))
+    if len(_SEQ_PLANS) > 64:
+        _SEQ_PLANS.clear()
+    _SEQ_PLANS[key] = (plan, mask)            # the mask stays referenced: its address is the key
+    return plan
+
+
+def pack_rows(x, seq):
+    """[B, L, d] -> [1, N, d] (valid rows only); None stays None"""
+    if x is None:
+        return None
+    B, L, d = x.shape
+    return x.reshape(B * L, d).index_select(0, seq.idx).view(1, seq.N, d)
+
+
+def unpack_rows(x, seq):
+    """[1, N, d] -> [B, L, d] with zeros at the PAD positions"""
+    if x is None:
+        return None
+    d = x.shape[-1]
+    out = torch.zeros((seq.B * seq.L, d), dtype=x.dtype, device=x.device)
+    return out.index_copy(0, seq.idx, x.reshape(seq.N, d)).view(seq.B, seq.L, d)
+
+
 # ----------------------------------------------------------------------------- sub-layer Functions
 class SelfAttnLN(torch.autograd.Function):
     """y = LN(x + drop(out_proj(MHA_core(in_proj(x))))) ; returns (y, probs|None)"""
@@ -686,20 +783,27 @@ class SelfAttnLN(torch.autograd.Function):
         B, L, d = x.shape
         hd = _heads(d, H)
         M = B * L
+        # packed sequences (x is [1, N_valid, d], the kpm slot carries the Seq): the attention sees AB samples of up to AL rows
+        AB, AL, cu = B, L, None
+        if isinstance(kpm, Seq):
+            if need_w:
+                raise ValueError("attention maps are exported by the padded path only")
+            AB, AL, cu, kpm = kpm.B, kpm.Lmax, (kpm.cu, kpm.cu), None
         x2 = _contig_bf16(x).view(M, d)
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         qkv = proj_fwd(Operand(x2, mx_of(x)), sh, w_in, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        o, lse, mbits = attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off, want_bits=True) if attn_mask_bits(B, H, L, hd) else \
-            attn_fwd(q, k, v, B, H, L, L, hd, kpm, p, seed, site, b_off) + (None,)
+        o, lse, mbits = attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, AL, hd) else \
+            attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN,
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * AL, x32=x32v, want32=TWIN,
                                              want_mx=want_mx_copy(M, d))
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
+        ctx.packed = (AB, AL, cu)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
         return tag_mx(y.view(B, L, d), mx[0] if mx else None), (y32.view(B, L, d) if y32 is not None else None), probs
@@ -708,13 +812,14 @@ class SelfAttnLN(torch.autograd.Function):
     def backward(ctx, dy, dy32, _dprobs):
         x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, L, d, H, hd, p, seed, site, b_off = ctx.cfg
+        AB, AL, cu = ctx.packed
         M = B * L
         dev = x2.device
         dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(M, d)
         p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
-        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L,
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * AL,
                                                    outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
                                                    accumulate=acc, x32=x32v)
         dw_out = sink.buf(p_w_out)
@@ -723,7 +828,8 @@ class SelfAttnLN(torch.autograd.Function):
         dqkv = torch.empty((M, 3 * d), dtype=BF16, device=dev)
         db_in = sink.buf(p_b_in)
         folded = attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:],
-                          lse, B, H, L, L, hd, kpm, p, seed, site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits)
+                          lse, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits,
+                          cu=cu)
         dw_in = sink.buf(p_w_in)
         linear_dw(dqkv, x2, dw_in, acc)
         if not folded:
@@ -748,6 +854,13 @@ class CrossAttnLN(torch.autograd.Function):
         B, Lq, d = xq.shape
         Lk = xkv.shape[1]
         hd = _heads(d, H)
+        # packed sequences: the kpm slot carries (Seq of the query side, Seq of the key side)
+        AB, ALq, ALk, cu = B, Lq, Lk, None
+        if isinstance(kpm, tuple):
+            if need_w:
+                raise ValueError("attention maps are exported by the padded path only")
+            sq, sk = kpm
+            AB, ALq, ALk, cu, kpm = sq.B, sq.Lmax, sk.Lmax, (sq.cu, sk.cu), None
         xq2 = _contig_bf16(xq).view(B * Lq, d)
         xq32 = _c32(xq32)
         x32v = xq32.view(B * Lq, d) if xq32 is not None else None
@@ -756,14 +869,15 @@ class CrossAttnLN(torch.autograd.Function):
         q = proj_fwd(Operand(xq2, mx_of(xq)), sh, w_in, w_in16, b_in, rows=(0, d))
         kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
-        o, lse, mbits = attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=True) if attn_mask_bits(B, H, Lk, hd) else \
-            attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off) + (None,)
+        o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd) else \
+            attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * Lq, x32=x32v, want32=TWIN,
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * ALq, x32=x32v, want32=TWIN,
                                              want_mx=want_mx_copy(B * Lq, d))
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
+        ctx.packed = (AB, ALq, ALk, cu)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
         return tag_mx(y.view(B, Lq, d), mx[0] if mx else None), (y32.view(B, Lq, d) if y32 is not None else None), probs
@@ -772,12 +886,13 @@ class CrossAttnLN(torch.autograd.Function):
     def backward(ctx, dy, dy32, _dprobs):
         xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
+        AB, ALq, ALk, cu = ctx.packed
         dev = xq2.device
         dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(B * Lq, d)
         p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
-        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * Lq,
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * ALq,
                                                    outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
                                                    accumulate=acc, x32=x32v)
         dw_out = sink.buf(p_w_out)
@@ -786,8 +901,8 @@ class CrossAttnLN(torch.autograd.Function):
         dq = torch.empty((B * Lq, d), dtype=BF16, device=dev)
         dkv = torch.empty((B * Lk, 2 * d), dtype=BF16, device=dev)
         db_in = sink.buf(p_b_in)
-        folded = attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, B, H, Lq, Lk, hd, kpm, p, seed,
-                          site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits)
+        folded = attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, AB, H, ALq, ALk, hd, kpm, p, seed,
+                          site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits, cu=cu)
         dw_in = sink.buf(p_w_in)
         linear_dw(dq, xq2, dw_in[:d], acc)
         linear_dw(dkv, xkv2, dw_in[d:], acc)

@@ -43,7 +43,40 @@ struct AttnArgs {
   // (batch, head, query, 64-key tile): bit 16*g + 4*n + r  <->  key 64*tile + 16*n + 4*g + r (the forward's register order:
   // lane group g holds keys 4g..4g+3 of each 16-key subtile n).  NULL: the backward replays the hash.
   unsigned long long* mbits;
+  // Packed (varlen) sequences: rows of sample b are cu_q[b] .. cu_q[b+1]-1 of Q / O / dO / dQ and cu_k[b] .. cu_k[b+1]-1 of
+  // K / V / dK / dV (int32 [B+1] each, both set or both NULL); Lq / Lk are then the LONGEST sequences (grid size, and the row
+  // stride of the lse / delta / mask-word side buffers, which keep their padded [B,H,Lq] indexing).  Every length >= 1.
+  const int* cu_q;
+  const int* cu_k;
 };
+
+// Packed sequences: the kernels below index sample b's rows as b * L + r.  localize() turns the launch arguments into the view of
+// ONE (batch, head): L becomes this sample's length and every row pointer is shifted so that b * L + r lands on the packed row
+// cu[b] + r; the side buffers are shifted back onto their padded slots.  Blocks whose tile lies beyond the sample's length find
+// nothing to do (a.Lq / a.Lk bound every loop and store).  Scalar (per-block uniform) arithmetic only.
+__device__ __forceinline__ AttnArgs localize(const AttnArgs& a0, int b, int h) {
+  AttnArgs a = a0;
+  if (a0.cu_q != nullptr) {
+    const int q0 = a0.cu_q[b], k0 = a0.cu_k[b];
+    const int Lq = a0.cu_q[b + 1] - q0, Lk = a0.cu_k[b + 1] - k0;
+    const long sq = (long)q0 - (long)b * Lq, sk = (long)k0 - (long)b * Lk;
+    a.Q += sq * a.ldq;
+    if (a.O != nullptr) a.O += sq * a.ldo;
+    if (a.dO != nullptr) a.dO += sq * a.lddo;
+    if (a.dQ != nullptr) a.dQ += sq * a.lddq;
+    a.K += sk * a.ldk;
+    a.V += sk * a.ldv;
+    if (a.dK != nullptr) a.dK += sk * a.lddk;
+    if (a.dV != nullptr) a.dV += sk * a.lddv;
+    const long bh = (long)b * a.H + h;
+    if (a.lse != nullptr) a.lse += bh * (a0.Lq - Lq);
+    if (a.delta != nullptr) a.delta += bh * (a0.Lq - Lq);
+    if (a.mbits != nullptr) a.mbits += bh * ((long)a0.Lq * ((a0.Lk + 63) >> 6) - (long)Lq * ((Lk + 63) >> 6));
+    a.Lq = Lq; a.Lk = Lk;
+    a.kpm = nullptr;
+  }
+  return a;
+}
 
 // v_exp_f32 directly: arguments are <= 0 (or -inf), no denormal-range fix-up needed
 #define EXP2(x) __builtin_amdgcn_exp2f(x)
@@ -152,7 +185,7 @@ __device__ __forceinline__ void tile_and_head(int ntiles, int nbh, int& tile, in
 
 // ------------------------------------------------------------------------------------------ forward
 template <int HD, int NW, int QW, bool WB>     // WB: also write the dropout keep-mask as bit words (AttnArgs::mbits)
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a0) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   __shared__ __attribute__((aligned(16))) char lds[2 * 64 * STRIDE + 64 * 4 + 16];
@@ -163,8 +196,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
-  tile_and_head((a.Lq + NW * QW * 16 - 1) / (NW * QW * 16), a.B * a.H, tile, bh);
-  const int b = bh / a.H, h = bh - b * a.H;
+  tile_and_head((a0.Lq + NW * QW * 16 - 1) / (NW * QW * 16), a0.B * a0.H, tile, bh);
+  const int b = bh / a0.H, h = bh - b * a0.H;
+  const AttnArgs a = localize(a0, b, h);
+  if (tile * (NW * QW * 16) >= a.Lq) return;          // packed sequences: this sample is shorter than the longest one
   const int qbase = tile * (NW * QW * 16) + wave * QW * 16;
 
   bf16x8 qf[QW][KS];
@@ -361,7 +396,7 @@ __device__ __forceinline__ void block_colsum_store(f32x4 (&cs)[DT], float* red, 
 
 // ------------------------------------------------------------------------------------------ dQ (+ delta)
 template <int HD, int NW, int QW, bool BITS>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a0) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   __shared__ __attribute__((aligned(16))) char lds[2 * 64 * STRIDE + 64 * 4];
@@ -371,8 +406,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
-  tile_and_head((a.Lq + NW * QW * 16 - 1) / (NW * QW * 16), a.B * a.H, tile, bh);
-  const int b = bh / a.H, h = bh - b * a.H;
+  tile_and_head((a0.Lq + NW * QW * 16 - 1) / (NW * QW * 16), a0.B * a0.H, tile, bh);
+  const int b = bh / a0.H, h = bh - b * a0.H;
+  const AttnArgs a = localize(a0, b, h);
+  float* const csq_row = a.csq != nullptr ? a.csq + (long)(b * gridDim_tiles(a0.Lq, NW * QW * 16) + tile) * ((long)a.H * HD) + h * HD : nullptr;
+  if (tile * (NW * QW * 16) >= a.Lq) {                 // packed sequences: no query of this sample in the tile
+    if (csq_row != nullptr) for (int e = tid; e < HD; e += NT) csq_row[e] = 0.f;
+    return;
+  }
   const int qbase = tile * (NW * QW * 16) + wave * QW * 16;
 
   bf16x8 qf[QW][KS], dof[QW][KS];
@@ -537,7 +578,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
   }
   if (a.csq != nullptr) {          // kernel-uniform
     __syncthreads();                // every wave is done with the K/V tiles
-    block_colsum_store<DT, NW>(cs, (float*)lds, a.csq + (long)(b * gridDim_tiles(a.Lq, NW * QW * 16) + tile) * ((long)a.H * HD) + h * HD, tid);
+    block_colsum_store<DT, NW>(cs, (float*)lds, csq_row, tid);
   }
 }
 
@@ -545,7 +586,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a) 
 // The round-1 kernel, kept as it was tuned: the default backward (hash replay, dQ from its own kernel).  The kernel after it adds
 // the bit-word mask and the fused dQ; its different tile pipeline costs this one's register budget (3 blocks per CU at head_dim 96).
 template <int HD, int NW, int KW, int QT>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnArgs a0) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32 || QT == 64, "query tile");
@@ -556,8 +597,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnAr
   __shared__ __attribute__((aligned(16))) char lds[2 * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
-  tile_and_head((a.Lk + NW * KW * 16 - 1) / (NW * KW * 16), a.B * a.H, tile, bh);
-  const int b = bh / a.H, h = bh - b * a.H;
+  tile_and_head((a0.Lk + NW * KW * 16 - 1) / (NW * KW * 16), a0.B * a0.H, tile, bh);
+  const int b = bh / a0.H, h = bh - b * a0.H;
+  const AttnArgs a = localize(a0, b, h);
+  float* const cskv_row = a.cskv != nullptr ? a.cskv + (long)(b * gridDim_tiles(a0.Lk, NW * KW * 16) + tile) * (2L * a.H * HD) + h * HD : nullptr;
+  if (tile * (NW * KW * 16) >= a.Lk) {                 // packed sequences: no key of this sample in the tile
+    if (cskv_row != nullptr) for (int e = tid; e < HD; e += NT) { cskv_row[e] = 0.f; cskv_row[(long)a.H * HD + e] = 0.f; }
+    return;
+  }
   const int kbase = tile * (NW * KW * 16) + wave * KW * 16;
 
   bf16x8 kreg[KW][KS], vreg[KW][KS];
@@ -717,7 +764,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnAr
     }
   }
   if (a.cskv != nullptr) {         // kernel-uniform
-    float* row = a.cskv + (long)(b * gridDim_tiles(a.Lk, NW * KW * 16) + tile) * (2L * a.H * HD) + h * HD;
+    float* row = cskv_row;
     __syncthreads();
     block_colsum_store<DT, NW>(csk, (float*)lds, row, tid);
     block_colsum_store<DT, NW>(csv, (float*)lds + NW * DT * 16, row + (long)a.H * HD, tid);
@@ -735,10 +782,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnAr
 //          [16 query x HD/2] slice of dQ = dS.K over all NK keys (K^T fragments by transposed reads of the block's K tile)
 //          and stores it.  delta = rowsum(dO * O) is computed here as well (8 lanes per query row).
 // Per query row the Q image's 32 pad bytes carry the row's sideband: {lse', delta', keep-mask dwords [tile][half]}.
-template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED, bool PAIR = false>
+// PACKED: cu_seqlens launch (localize()); a separate instantiation because this kernel runs at the 256-register limit and the
+// per-sample pointers of the packed view cost the padded launch 13 us of 82 (a2t backward at cfg 2) when they share one body
+template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED, bool PAIR = false, bool PACKED = false>
 // two waves per SIMD are only requested where the kernel fits 256 registers WITHOUT spilling: co-resident blocks of the spilling
 // builds gave wrong dS elements on hardware (scripts_dev/dbg_attn.py; a single block per CU of the same code was exact)
-__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <= 96 && NW == 4 && KW == 1) ? 3 : ((PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED)))) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <= 96 && NW == 4 && KW == 1) ? 3 : ((PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED)))) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a0) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32, "query tile");
@@ -764,8 +813,14 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
   char* const dSt0 = Ktile + KT_BYTES;
   const int tid = PAIR ? (int)(threadIdx.x % (NW * 64)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
   int tile, bh;
-  tile_and_head((a.Lk + NK - 1) / NK, a.B * a.H, tile, bh, PAIR ? (int)blockIdx.x * 2 + sub : (int)blockIdx.x);
-  const int b = bh / a.H, h = bh - b * a.H;
+  tile_and_head((a0.Lk + NK - 1) / NK, a0.B * a0.H, tile, bh, PAIR ? (int)blockIdx.x * 2 + sub : (int)blockIdx.x);
+  const int b = bh / a0.H, h = bh - b * a0.H;
+  const AttnArgs a = PACKED ? localize(a0, b, h) : a0;
+  float* const cskv_row = a.cskv != nullptr ? a.cskv + (long)(b * gridDim_tiles(a0.Lk, NK) + tile) * (2L * a.H * HD) + h * HD : nullptr;
+  if (!FUSED && tile * NK >= a.Lk) {                   // packed sequences: no key of this sample in the tile (fused: one tile holds them all)
+    if (cskv_row != nullptr) for (int e = tid; e < HD; e += NT) { cskv_row[e] = 0.f; cskv_row[(long)a.H * HD + e] = 0.f; }
+    return;
+  }
   const int kbase = tile * NK + wave * KW * 16;
 
   bf16x8 kreg[FUSED ? 1 : KW][FUSED ? 1 : KS], vreg[KW][KS];
@@ -1057,7 +1112,7 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
     }
   }
   if (a.cskv != nullptr) {         // kernel-uniform
-    float* row = a.cskv + (long)(b * gridDim_tiles(a.Lk, NK) + tile) * (2L * a.H * HD) + h * HD;
+    float* row = cskv_row;
     __syncthreads();
     block_colsum_store<DT, NW>(csk, (float*)lds, row, tid);
     block_colsum_store<DT, NW>(csv, (float*)lds + NW * DT * 16, row + (long)a.H * HD, tid);
@@ -1203,18 +1258,25 @@ static void fill_drop(AttnArgs& a, float p, uint64_t seed, const unsigned long l
 
 extern "C" long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk) { return (long)B * H * Lq * ((Lk + 63) / 64) * 8; }
 
-extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
-                               long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
-                               int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
-                               unsigned site, int b_offset, void* drop_mask_bits, hipStream_t st) {
+static int check_packed(const AttnArgs& a) {
+  HRIEMO_CHECK((a.cu_q == nullptr) == (a.cu_k == nullptr), "attn: cu_seqlens_q and cu_seqlens_k must be given together");
+  HRIEMO_CHECK(a.cu_q == nullptr || a.kpm == nullptr, "attn: packed sequences carry their lengths, a key_padding_mask cannot be combined with them");
+  return 0;
+}
+
+static int attn_fwd_impl(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                         long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
+                         int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                         unsigned site, int b_offset, void* drop_mask_bits, const int* cu_q, const int* cu_k, hipStream_t st) {
   AttnArgs a = {};
+  a.cu_q = cu_q; a.cu_k = cu_k;
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
   a.kpm = key_padding_mask; a.lse = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
   fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
   a.mbits = (unsigned long long*)drop_mask_bits;
-  if (check_common(a, head_dim)) return 1;
+  if (check_common(a, head_dim) || check_packed(a)) return 1;
   HRIEMO_CHECK(ldo % 4 == 0 && ((uintptr_t)O % 8) == 0 && ((uintptr_t)drop_mask_bits % 8) == 0, "attn_fwd: unaligned O / mask bits");
   hriemo_prof_begin(HP_ATTN_FWD, st);
   // two 16-row query sub-tiles per wave (K/V fragment reuse) unless the key loop is short and the 128-row tiles pad the
@@ -1241,6 +1303,23 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_LAUNCH_CHECK("attn_fwd_kernel");
   hriemo_prof_end(HP_ATTN_FWD, st, 4.0 * B * H * (double)Lq * Lk * head_dim);
   return 0;
+}
+
+extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                               long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
+                               int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                               unsigned site, int b_offset, void* drop_mask_bits, hipStream_t st) {
+  return attn_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, key_padding_mask, lse, B, H, Lq, Lk, head_dim, p_drop, seed, seed_dev, site,
+                       b_offset, drop_mask_bits, nullptr, nullptr, st);
+}
+extern "C" int hriemo_attn_fwd_varlen(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                                      long ldo, const int* cu_seqlens_q, const int* cu_seqlens_k, float* lse, int B, int H,
+                                      int max_len_q, int max_len_k, int head_dim, float p_drop, unsigned long long seed,
+                                      const unsigned long long* seed_dev, unsigned site, int b_offset, void* drop_mask_bits,
+                                      hipStream_t st) {
+  HRIEMO_CHECK(cu_seqlens_q != nullptr && cu_seqlens_k != nullptr, "attn_fwd_varlen: cu_seqlens missing");
+  return attn_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, nullptr, lse, B, H, max_len_q, max_len_k, head_dim, p_drop, seed, seed_dev,
+                       site, b_offset, drop_mask_bits, cu_seqlens_q, cu_seqlens_k, st);
 }
 
 // Backward tile width for a row side of length L (queries for dQ, keys for dK/dV).  Narrow blocks (64 rows, ~160
@@ -1272,25 +1351,27 @@ static bool bwd_wide(int L, int BH, int head_dim) {
 // launch with the bit-word mask at two waves per SIMD; traced (scripts_dev/dbg_attn.py) to the compiler's packed form of the
 // (dP - delta') subtraction, pinned to v_sub_f32 in the kernel since; 4.4e9 elements bit-identical between the bit-word and the
 // hash variant afterwards (scripts_dev/soak_attn.py, profiles/r02_attn_soak.log).
-static bool bwd_fused(int Lk, int head_dim, int BH) {
+static bool bwd_fused(int Lk, int head_dim, int B, int H) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
-  // (an odd number of (batch, head) problems cannot be paired: two-kernel path)
-  return on && Lk > 16 && Lk <= 128 && head_dim >= 32 && (BH % 2 == 0 || (head_dim == 128 && Lk > 64));
+  // (the paired kernel puts heads 2j, 2j+1 of ONE sample into a workgroup -- same trip counts also with packed sequences of
+  // different lengths; an odd number of heads cannot be paired: two-kernel path)
+  (void)B;
+  return on && Lk > 16 && Lk <= 128 && head_dim >= 32 && (H % 2 == 0 || (head_dim == 128 && Lk > 64));
 }
 
-extern "C" int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim) { return bwd_fused(Lk, head_dim, B * H) ? 1 : 0; }
+extern "C" int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim) { return bwd_fused(Lk, head_dim, B, H) ? 1 : 0; }
 
 // rows of the column-sum partials hriemo_attn_bwd leaves behind: dK|dV side (sequence of length Lk) ...
 extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {
-  if (bwd_fused(L, head_dim, B * H)) return B;
+  if (bwd_fused(L, head_dim, B, H)) return B;
   if (bwd_wide(L, B * H, head_dim)) return B * ((L + 127) / 128);
   if (L > 16) return B * ((L + 63) / 64);
   return B;
 }
 // ... and dQ side (depends on both lengths: the fused kernel writes one row per (batch, head))
 extern "C" int hriemo_attn_bwd_dq_colsum_rows(int B, int H, int Lq, int Lk, int head_dim) {
-  if (bwd_fused(Lk, head_dim, B * H)) return B;
+  if (bwd_fused(Lk, head_dim, B, H)) return B;
   if (bwd_wide(Lq, B * H, head_dim)) return B * ((Lq + 127) / 128);
   if (Lq > 16) return B * ((Lq + 63) / 64);
   return B;
@@ -1304,13 +1385,15 @@ extern "C" int hriemo_attn_bwd_dq_colsum_rows(int B, int H, int Lq, int Lk, int 
     case 128: { CALL(128); } break;         \
   }
 
-extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
-                               const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
-                               long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
-                               const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
-                               float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
-                               float* dq_colsum_partials, float* dkv_colsum_partials, const void* drop_mask_bits, hipStream_t st) {
+static int attn_bwd_impl(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                         const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
+                         long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
+                         const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
+                         float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                         float* dq_colsum_partials, float* dkv_colsum_partials, const void* drop_mask_bits, const int* cu_q,
+                         const int* cu_k, hipStream_t st) {
   AttnArgs a = {};
+  a.cu_q = cu_q; a.cu_k = cu_k;
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
   a.csq = dq_colsum_partials; a.cskv = dkv_colsum_partials;
@@ -1320,12 +1403,12 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   a.scale = 1.0f / sqrtf((float)head_dim);
   fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
   a.mbits = (unsigned long long*)drop_mask_bits;
-  if (check_common(a, head_dim)) return 1;
+  if (check_common(a, head_dim) || check_packed(a)) return 1;
   HRIEMO_CHECK(ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, "attn_bwd: bad leading dims");
   HRIEMO_CHECK(((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 && ((uintptr_t)dQ % 8) == 0 &&
                    ((uintptr_t)dK % 8) == 0 && ((uintptr_t)dV % 8) == 0 && ((uintptr_t)drop_mask_bits % 8) == 0, "attn_bwd: unaligned operand");
   const bool bits = a.thr16 != 0 && a.mbits != nullptr;
-  if (bwd_fused(Lk, head_dim, B * H)) {
+  if (bwd_fused(Lk, head_dim, B, H)) {
     hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
     // PAIR (two (batch, head) problems per workgroup, one workgroup per CU) whenever two problems fit the CU's LDS; otherwise a
     // problem needs more than half the LDS and is alone on its CU anyway
@@ -1333,10 +1416,14 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   {                                                                                                                              \
     constexpr int lds_one__ = 4 * 32 * AttnGeom<HD>::STRIDE + (4 * KW_ * 16) * AttnGeom<HD>::STRIDE + 2 * (4 * KW_ * 16) * 96;     \
     if constexpr (2 * lds_one__ <= 160 * 1024) {                                                                                 \
-      if ((B * H) % 2 == 0) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true>), dim3(B * H / 2), dim3(512), 0, st, a); \
+      if ((B * H) % 2 == 0) {                                                                                                    \
+        if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true, true>), dim3(B * H / 2), dim3(512), 0, st, a); \
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true>), dim3(B * H / 2), dim3(512), 0, st, a);   \
+      }                                                                                                                          \
       else { hriemo_set_error("attn_bwd: internal: odd (batch, head) count reached the paired kernel"); return 1; }            \
     } else {                                                                                                                     \
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);             \
+      if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false, true>), dim3(B * H), dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);        \
     }                                                                                                                            \
   }
     if (Lk <= 64) {
@@ -1402,7 +1489,9 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
   if (bwd_wide(Lk, B * H, head_dim)) {
     if (bits) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32, true, false>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
+#define CALL(HD)                                                                                                             \
+  if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32, true, false, false, true>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a); \
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 2, 32, true, false>), dim3(((Lk + 127) / 128) * B * H), dim3(256), 0, st, a)
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     } else {
@@ -1412,7 +1501,9 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
     }
   } else if (Lk > 16) {
     if (bits) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, 32, true, false>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
+#define CALL(HD)                                                                                                             \
+  if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, 32, true, false, false, true>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a); \
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, 1, 32, true, false>), dim3(((Lk + 63) / 64) * B * H), dim3(256), 0, st, a)
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     } else {
@@ -1422,7 +1513,9 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
     }
   } else {
     if (bits) {
-#define CALL(HD) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32, true, false>), dim3(B * H), dim3(64), 0, st, a)
+#define CALL(HD)                                                                                                             \
+  if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32, true, false, false, true>), dim3(B * H), dim3(64), 0, st, a); \
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 1, 1, 32, true, false>), dim3(B * H), dim3(64), 0, st, a)
       DISPATCH_HD(head_dim, CALL)
 #undef CALL
     } else {
@@ -1434,6 +1527,29 @@ extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk,
   HRIEMO_LAUNCH_CHECK("attn_bwd_dkv_kernel");
   hriemo_prof_end(HP_ATTN_BWD_DKV, st, 8.0 * B * H * (double)Lq * Lk * head_dim);
   return 0;
+}
+
+extern "C" int hriemo_attn_bwd(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                               const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
+                               long lddk, void* dV, long lddv, const unsigned char* key_padding_mask,
+                               const float* lse, float* delta, int B, int H, int Lq, int Lk, int head_dim,
+                               float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                               float* dq_colsum_partials, float* dkv_colsum_partials, const void* drop_mask_bits, hipStream_t st) {
+  return attn_bwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, key_padding_mask, lse, delta, B, H, Lq,
+                       Lk, head_dim, p_drop, seed, seed_dev, site, b_offset, dq_colsum_partials, dkv_colsum_partials, drop_mask_bits,
+                       nullptr, nullptr, st);
+}
+extern "C" int hriemo_attn_bwd_varlen(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv,
+                                      const void* O, long ldo, const void* dO, long lddo, void* dQ, long lddq, void* dK,
+                                      long lddk, void* dV, long lddv, const int* cu_seqlens_q, const int* cu_seqlens_k,
+                                      const float* lse, float* delta, int B, int H, int max_len_q, int max_len_k, int head_dim,
+                                      float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
+                                      int b_offset, float* dq_colsum_partials, float* dkv_colsum_partials,
+                                      const void* drop_mask_bits, hipStream_t st) {
+  HRIEMO_CHECK(cu_seqlens_q != nullptr && cu_seqlens_k != nullptr, "attn_bwd_varlen: cu_seqlens missing");
+  return attn_bwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, nullptr, lse, delta, B, H, max_len_q,
+                       max_len_k, head_dim, p_drop, seed, seed_dev, site, b_offset, dq_colsum_partials, dkv_colsum_partials,
+                       drop_mask_bits, cu_seqlens_q, cu_seqlens_k, st);
 }
 
 extern "C" int hriemo_attn_probs(const void* Q, long ldq, const void* K, long ldk, const unsigned char* key_padding_mask,

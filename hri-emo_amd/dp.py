@@ -218,6 +218,7 @@ class DataParallelStep:
         finally:
             _ops.CAPTURING = False
         _ops.GRAPHS_ALIVE += 1            # from now on outgrown workspaces are retired, not freed (_ops.workspace)
+        self._packed = _ops.varlen()      # the graph bakes the sequence lengths of THIS batch in (packed rows, cu_seqlens)
         self._graph = graph
         self._replay = True
 
@@ -229,8 +230,14 @@ class DataParallelStep:
 
     def step(self, h_a, h_t, m_a, m_t, y):
         if self._graph is not None and getattr(self, "_replay", True):
-            for s, t in zip(self._static, (h_a, h_t, m_a, m_t, y)):
+            for k, (s, t) in enumerate(zip(self._static, (h_a, h_t, m_a, m_t, y))):
                 if s is not None and t is not None and s.data_ptr() != t.data_ptr():
+                    if getattr(self, "_packed", False) and k in (2, 3):
+                        if not torch.equal(s, t.to(s.dtype)):
+                            raise RuntimeError("DataParallelStep: this step was captured with packed (varlen) sequences; its graph can "
+                                               "only be replayed with the padding masks it was captured with -- use_graph(False) or "
+                                               "capture per length pattern")
+                        continue
                     s.copy_(t)
             self._graph.replay()
             self.buckets.finish()

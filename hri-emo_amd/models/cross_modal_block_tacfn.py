@@ -51,11 +51,18 @@ class CrossModalBlock(nn.Module):
         return _ops.FFNLN.apply(x, x32, ffn[0].weight, ffn[0].bias, ffn[2].weight, ffn[2].bias, ln.weight, ln.bias,
                                 self._sh, p, 0.0, seed, site, self.batch_offset)
 
-    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
-        """(bf16, fp32-twin) pairs in and out; returns (a, a32, t, t32, maps|None)"""
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, plan=None):
+        """(bf16, fp32-twin) pairs in and out; returns (a, a32, t, t32, maps|None).
+        plan = (Seq audio, Seq text): a / t hold the packed valid rows ([1, N, d], _ops.pack_rows) and the attention kernels get
+        cu_seqlens instead of padding masks."""
         B, La, _ = a.shape
         Lt = t.shape[1]
-        kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
+        if plan is not None:
+            kpm_a, kpm_t = plan                 # self-attention: the Seq itself; cross-attention: (query side, key side)
+            kpm_a2t, kpm_t2a = (plan[0], plan[1]), (plan[1], plan[0])
+        else:
+            kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
+            kpm_a2t, kpm_t2a = kpm_t, kpm_a
         p = self.p if self.training else 0.0
         seed = _ops.next_seed(self.training and p > 0)
         s = self._site
@@ -69,9 +76,9 @@ class CrossModalBlock(nn.Module):
         if side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
             t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
-            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)  # :98-105
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need)  # :98-105
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
-            x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)  # :111-118
+            x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need)  # :111-118
             t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
         else:
             # The audio and text branches only meet at the two cross-attentions (each reads the OTHER branch's
@@ -93,9 +100,9 @@ class CrossModalBlock(nn.Module):
                 _ops.share(t_s32, main)
                 _ops.share(a_s32, side)
             with torch.cuda.stream(side):
-                x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_a, p, seed, s[4], need)
+                x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need)
                 t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])
-            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_t, p, seed, s[2], need)
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need)
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])
             main.wait_stream(side)
             for x_ in (t_cm, t_cm32, w_t, w_t2a):
@@ -121,10 +128,22 @@ class CrossModalTransformer(nn.Module):
 
     def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
         all_layers_attn = []
+        plan = None
+        if _ops.varlen() and not need and mask_a is not None and mask_t is not None and _ops.precision() == "bf16":
+            # the encoder on the valid rows only (prefix masks, as the collate builds them); anything else
+            # takes the padded path
+            sa = _ops.seq_plan(mask_a, a.shape[0], a.shape[1])
+            st = _ops.seq_plan(mask_t, t.shape[0], t.shape[1])
+            if sa is not None and st is not None:
+                plan = (sa, st)
+                a, a32, t, t32 = _ops.pack_rows(a, sa), _ops.pack_rows(a32, sa), _ops.pack_rows(t, st), _ops.pack_rows(t32, st)
         for layer in self.layers:
-            a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+            a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need, plan)
             if need:
                 all_layers_attn.append(maps)
+        if plan is not None:
+            a, a32 = _ops.unpack_rows(a, plan[0]), _ops.unpack_rows(a32, plan[0])
+            t, t32 = _ops.unpack_rows(t, plan[1]), _ops.unpack_rows(t32, plan[1])
         return a, a32, t, t32, all_layers_attn
 
     def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):

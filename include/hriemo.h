@@ -88,6 +88,24 @@ long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk);
 /* 1 when hriemo_attn_bwd runs as the single kernel for this problem (the bit words pay there; the two-kernel path is as fast
  * replaying the hash) -- what the host side asks before it requests drop_mask_bits from the forward */
 int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim);
+/* Packed (varlen) sequences, SURVEY 8(f) rank 4: the reference pads every sample to the batch maximum
+ * (scripts/fusion/train_fusion_seq_level_decoder.py:191-232) and computes the PAD rows; here Q / O / dO / dQ hold the valid rows of
+ * all samples back to back (sample b = rows cu_seqlens_q[b] .. cu_seqlens_q[b+1]-1) and K / V / dK / dV likewise with
+ * cu_seqlens_k (int32 [B+1], device memory, every length >= 1).  max_len_q / max_len_k are the longest sequences: they size the
+ * grid and are the row stride of lse / delta / drop_mask_bits and of the column-sum partials, which keep the padded indexing of
+ * the functions above (so hriemo_attn_mask_bytes / *_colsum_rows are asked with the maxima).  Same arithmetic, same dropout
+ * mask (it is keyed by position within the sequence), results on the valid rows identical to the padded call with a
+ * key_padding_mask. */
+int hriemo_attn_fwd_varlen(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
+                           const int* cu_seqlens_q, const int* cu_seqlens_k, float* lse, int B, int H, int max_len_q,
+                           int max_len_k, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                           unsigned site, int b_offset, void* drop_mask_bits, hriemo_stream_t stream);
+int hriemo_attn_bwd_varlen(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, const void* O, long ldo,
+                           const void* dO, long lddo, void* dQ, long lddq, void* dK, long lddk, void* dV, long lddv,
+                           const int* cu_seqlens_q, const int* cu_seqlens_k, const float* lse, float* delta, int B, int H,
+                           int max_len_q, int max_len_k, int head_dim, float p_drop, unsigned long long seed,
+                           const unsigned long long* seed_dev, unsigned site, int b_offset, float* dq_colsum_partials,
+                           float* dkv_colsum_partials, const void* drop_mask_bits, hriemo_stream_t stream);
 /* Optional by-product of hriemo_attn_bwd (either pointer may be NULL): per-block column sums of the dQ tiles,
  * [hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, head_dim), H*head_dim] fp32, and of the dK | dV tiles,
  * [hriemo_attn_bwd_colsum_rows(B, H, Lk, head_dim), 2*H*head_dim] fp32 (values before their bf16 rounding).  Summed over rows

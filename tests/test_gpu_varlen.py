@@ -1,0 +1,195 @@
+"""GPU suite of the packed (varlen) path, SURVEY 8(f) rank 4: the encoder on the valid rows only (hriemo_attn_*_varlen with
+cu_seqlens, GEMM / LayerNorm / FFN on [N_valid, d]) must return what the padded path returns on every valid row -- kernels first
+(bit for bit), then the modules on the reference's ragged golden fixtures and a training step's gradients."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import hri_emo_oracle as O          # the checker (tests only)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def H():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import hri_emo_amd
+    yield hri_emo_amd
+    hri_emo_amd.set_varlen(False)
+
+
+def cu(t):
+    return None if t is None else t.cuda()
+
+
+@pytest.mark.parametrize("B,H_,Lq,Lk,hd,p", [(5, 8, 100, 40, 96, 0.1), (4, 8, 128, 128, 96, 0.1), (6, 4, 333, 100, 64, 0.0), (3, 8, 50, 400, 96, 0.1),
+                                              (7, 2, 70, 70, 32, 0.2), (3, 3, 40, 90, 128, 0.1), (4, 8, 6, 77, 16, 0.1)])
+def test_attention_varlen_equals_padded_on_valid_rows(H, B, H_, Lq, Lk, hd, p):
+    from hri_emo_amd import _ops as ops
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    d = H_ * hd
+    lq = torch.randint(1, Lq + 1, (B,), generator=g); lk = torch.randint(1, Lk + 1, (B,), generator=g)
+    lq[0], lk[0] = Lq, Lk                                   # the longest sample defines the padded shape
+    if B > 2:
+        lq[1], lk[1] = 1, 1                                 # and a one-row sample
+    q = (torch.randn(B, Lq, d, generator=g) * 1.5).bfloat16().cuda()
+    kv = torch.randn(B, Lk, 2 * d, generator=g).bfloat16().cuda()
+    do = torch.randn(B, Lq, d, generator=g).bfloat16().cuda()
+    vq = (torch.arange(Lq)[None] < lq[:, None]).cuda(); vk = (torch.arange(Lk)[None] < lk[:, None]).cuda()
+    do = do * vq[:, :, None]                              # PAD query rows carry no gradient in the model (nothing reads them)
+    kpm = (~vk).view(torch.uint8)
+    seed, site, boff = 987654321, 12, 3
+    # padded reference run (our own padded kernels with a key padding mask)
+    q2, kv2, do2 = q.view(B * Lq, d), kv.view(B * Lk, 2 * d), do.view(B * Lq, d)
+    o, lse, mb = ops.attn_fwd(q2, kv2[:, :d], kv2[:, d:], B, H_, Lq, Lk, hd, kpm, p, seed, site, boff, want_bits=True)
+    dq = torch.empty_like(q2); dkv = torch.empty_like(kv2)
+    ops.attn_bwd(q2, kv2[:, :d], kv2[:, d:], o, do2, dq, dkv[:, :d], dkv[:, d:], lse, B, H_, Lq, Lk, hd, kpm, p, seed, site, boff, mask_bits=mb)
+    # packed run
+    iq, ik = vq.reshape(-1).nonzero().reshape(-1), vk.reshape(-1).nonzero().reshape(-1)
+    cq = torch.zeros(B + 1, dtype=torch.int32); cq[1:] = torch.cumsum(lq, 0)
+    ck = torch.zeros(B + 1, dtype=torch.int32); ck[1:] = torch.cumsum(lk, 0)
+    cq, ck = cq.cuda(), ck.cuda()
+    qp, kvp, dop = q2.index_select(0, iq).contiguous(), kv2.index_select(0, ik).contiguous(), do2.index_select(0, iq).contiguous()
+    for use_bits in (True, False):
+        op, lsep, mbp = ops.attn_fwd(qp, kvp[:, :d], kvp[:, d:], B, H_, Lq, Lk, hd, None, p, seed, site, boff, want_bits=True, cu=(cq, ck))
+        dqp = torch.empty_like(qp); dkvp = torch.empty_like(kvp)
+        ops.attn_bwd(qp, kvp[:, :d], kvp[:, d:], op, dop, dqp, dkvp[:, :d], dkvp[:, d:], lsep, B, H_, Lq, Lk, hd, None, p, seed, site, boff,
+                     mask_bits=mbp if use_bits else None, cu=(cq, ck))
+        assert torch.equal(op, o.index_select(0, iq)), "O"
+        vq3 = vq[:, None, :].expand(B, H_, Lq)
+        assert torch.equal(lsep[vq3], lse[vq3]), "lse"
+        assert torch.equal(dqp, dq.index_select(0, iq)), ("dQ", use_bits)
+        assert torch.equal(dkvp, dkv.index_select(0, ik)), ("dK|dV", use_bits)
+    # the padded run leaves exact zeros in dK / dV of PAD keys, nothing else to compare there
+    assert float(dkv.float()[(~vk).reshape(-1)].abs().max() if (~vk).any() else 0.0) == 0.0
+
+
+def test_attention_varlen_bias_colsums_match(H):
+    """the in-projection bias gradients come from the attention kernels' column-sum partials: packed == padded"""
+    from hri_emo_amd import _ops as ops
+    B, H_, Lq, Lk, hd, p = 6, 8, 200, 90, 96, 0.1
+    d = H_ * hd
+    g = torch.Generator().manual_seed(5)
+    lq = torch.randint(1, Lq + 1, (B,), generator=g); lk = torch.randint(1, Lk + 1, (B,), generator=g)
+    lq[0], lk[0] = Lq, Lk
+    q2 = torch.randn(B * Lq, d, generator=g).bfloat16().cuda(); kv2 = torch.randn(B * Lk, 2 * d, generator=g).bfloat16().cuda()
+    do2 = torch.randn(B * Lq, d, generator=g).bfloat16().cuda()
+    vq = (torch.arange(Lq)[None] < lq[:, None]).cuda(); vk = (torch.arange(Lk)[None] < lk[:, None]).cuda()
+    do2 = do2 * vq.reshape(-1, 1)                         # upstream gradient of PAD query rows is zero in the model
+    iq, ik = vq.reshape(-1).nonzero().reshape(-1), vk.reshape(-1).nonzero().reshape(-1)
+    cq = torch.zeros(B + 1, dtype=torch.int32); cq[1:] = torch.cumsum(lq, 0)
+    ck = torch.zeros(B + 1, dtype=torch.int32); ck[1:] = torch.cumsum(lk, 0)
+    res = []
+    for packed in (False, True):
+        if packed:
+            qq, kk, dd, kpm, cuu = q2.index_select(0, iq).contiguous(), kv2.index_select(0, ik).contiguous(), do2.index_select(0, iq).contiguous(), None, (cq.cuda(), ck.cuda())
+        else:
+            qq, kk, dd, kpm, cuu = q2, kv2, do2, (~vk).view(torch.uint8), None
+        o, lse = ops.attn_fwd(qq, kk[:, :d], kk[:, d:], B, H_, Lq, Lk, hd, kpm, p, 11, 3, 0, cu=cuu)
+        dq = torch.empty_like(qq); dkv = torch.empty_like(kk)
+        bq = torch.zeros(d, device="cuda"); bkv = torch.zeros(2 * d, device="cuda")
+        ops.attn_bwd(qq, kk[:, :d], kk[:, d:], o, dd, dq, dkv[:, :d], dkv[:, d:], lse, B, H_, Lq, Lk, hd, kpm, p, 11, 3, 0, bias_grad=(bq, bkv), cu=cuu)
+        res.append((bq.cpu(), bkv.cpu(), dq.float().sum(0).cpu(), dkv.float().sum(0).cpu()))
+    (bq0, bkv0, sq0, skv0), (bq1, bkv1, sq1, skv1) = res
+    tol = 2e-3
+    assert float((bq1 - bq0).abs().max()) <= tol * float(bq0.abs().max())
+    assert float((bkv1 - bkv0).abs().max()) <= tol * float(bkv0.abs().max())
+    assert float((bq1 - sq1).abs().max()) <= 2e-2 * float(sq1.abs().max())       # partials are sums of the unrounded values
+
+
+def _fusion(H, d, ne, p=0.1):
+    return O.closed_form_init_(H.FusionWithEmotionDecoder(d_model=d, num_emotions=ne, n_heads=8, dropout=p)).cuda()
+
+
+@pytest.mark.parametrize("name,d,ne", [("cfg1_eval_ragged", 128, 4), ("hd96_eval_ragged", 768, 6)])
+def test_fusion_eval_varlen_equals_padded_and_golden(H, name, d, ne):
+    g = load_golden(name)
+    m = _fusion(H, d, ne).eval()
+    args = (cu(g["h_a"]), cu(g["h_t"]), cu(g["mask_a"]), cu(g["mask_t"]))
+    with torch.no_grad():
+        H.set_varlen(False)
+        ref = m(*args)
+        H.set_varlen(True)
+        got = m(*args)
+    from hri_emo_amd import _ops
+    assert _ops.seq_plan(args[2], *args[2].shape) is not None, "the fixture's masks are prefix masks: the packed path must have run"
+    valid = 1.0 - g["mask_a"].float().mean().item()
+    for a, b, what in zip(got, ref, ("logits", "beta", "z")):
+        assert float((a.float() - b.float()).abs().max()) <= 1e-5 * max(1.0, float(b.float().abs().max())), what
+    for a, what in zip(got, ("logits", "beta", "z")):
+        r = g[what]
+        assert float((a.float().cpu() - r).abs().max()) <= 5e-3 * max(1.0, float(r.abs().max())), what
+    print(f"{name}: packed == padded; valid audio fraction {valid:.2f}")
+
+
+def test_varlen_falls_back_on_masks_that_are_not_prefixes(H):
+    from hri_emo_amd import _ops
+    g = load_golden("cfg1_eval_ragged")
+    m = _fusion(H, 128, 4).eval()
+    ma = g["mask_a"].clone()
+    ma[0, 3] = True                                   # a hole inside the valid prefix
+    assert _ops.seq_plan(ma.cuda(), *ma.shape) is None
+    with torch.no_grad():
+        H.set_varlen(False)
+        ref = m(cu(g["h_a"]), cu(g["h_t"]), cu(ma), cu(g["mask_t"]))
+        H.set_varlen(True)
+        got = m(cu(g["h_a"]), cu(g["h_t"]), cu(ma), cu(g["mask_t"]))
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+def test_train_step_gradients_varlen_vs_padded(H):
+    """dropout 0: every parameter gradient of the packed step equals the padded step's to fp32 summation-order tolerance (the
+    weight-gradient GEMMs contract over N_valid rows instead of B*L rows whose PAD entries contribute exact zeros)"""
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(3)
+    kw = dict(d_model=256, num_emotions=5, n_heads=8, dropout=0.0)
+    m = H.FusionWithEmotionDecoder(**kw).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    B, Ta, Tt, d = 6, 150, 60, 256
+    h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda(), torch.randn(B, Tt, d, generator=g).cuda()
+    la = torch.randint(40, Ta + 1, (B,), generator=g); lt = torch.randint(10, Tt + 1, (B,), generator=g)
+    la[0], lt[0] = Ta, Tt
+    m_a, m_t = (torch.arange(Ta)[None] >= la[:, None]).cuda(), (torch.arange(Tt)[None] >= lt[:, None]).cuda()
+    y = (torch.rand(B, 5, generator=g) < 0.3).float().cuda()
+    grads = []
+    for packed in (False, True):
+        H.set_varlen(packed)
+        m.zero_grad(set_to_none=True)
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+        loss = fusion_step_loss(logits, beta, y)
+        loss.backward()
+        grads.append(({n: p.grad.detach().float().clone() for n, p in m.named_parameters()}, float(loss)))
+    (g0, l0), (g1, l1) = grads
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0))
+    worst = 0.0
+    for n in g0:
+        rel = float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-20))
+        worst = max(worst, rel)
+        assert rel <= 1e-5, (n, rel)          # measured 1.2e-7 (fp32 summation order of the weight-gradient GEMMs)
+    print(f"packed vs padded gradients: worst relative L2 difference {worst:.2e}; valid fraction audio {float(la.sum()) / (B * Ta):.2f} text {float(lt.sum()) / (B * Tt):.2f}")
+
+
+def test_captured_step_refuses_other_masks_in_packed_mode(H):
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.1).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    B, Ta, Tt, d = 4, 64, 32, 128
+    h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda().bfloat16(), torch.randn(B, Tt, d, generator=g).cuda().bfloat16()
+    m_a = (torch.arange(Ta)[None] >= torch.tensor([64, 30, 50, 10])[:, None]).cuda()
+    m_t = (torch.arange(Tt)[None] >= torch.tensor([32, 8, 20, 5])[:, None]).cuda()
+    y = (torch.rand(B, 4, generator=g) < 0.3).float().cuda()
+    H.set_varlen(True)
+    dp = DataParallelStep(m, fusion_step_loss, overlap=False)
+    dp.set_global_batch(B)
+    eager = float(dp.step(h_a, h_t, m_a, m_t, y))
+    dp.capture(h_a, h_t, m_a, m_t, y)
+    l1 = float(dp.step(h_a, h_t, m_a.clone(), m_t.clone(), y))          # same masks in other tensors: fine
+    assert math.isfinite(l1) and abs(l1 - eager) < 0.5
+    other = m_a.clone(); other[1, 30:40] = False
+    with pytest.raises(RuntimeError, match="packed"):
+        dp.step(h_a, h_t, other, m_t, y)
