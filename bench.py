@@ -268,6 +268,26 @@ def main():
         del snap
         log(f"optimizer (clip 5.0 + AdamW, hri_emo_amd.optim.FusedClipAdamW) {opt_ms:.3f} ms/step, reported separately")
 
+    # host -> device hand-over of one batch (features + masks + labels from pinned host memory), timed separately: `value` is
+    # quoted with the inputs resident in HBM; this is the PCIe-inclusive rate DESIGN.md notes (copy not overlapped with compute)
+    h2d = None
+    if rank == 0 and not a.no_roofline:
+        host = [t.cpu().pin_memory() for t in batch]
+        dst = [torch.empty_like(t) for t in batch]
+        for i in range(6):
+            if i == 1:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            for h_, d_ in zip(host, dst):
+                d_.copy_(h_, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t1) / 5 * 1e3
+        nbytes = sum(t.numel() * t.element_size() for t in batch)
+        h2d = {"h2d_ms_per_batch": round(h2d_ms, 3), "bytes": nbytes, "gb_per_s": round(nbytes / h2d_ms / 1e6, 1),
+               "value_with_serial_h2d": round(B / ((ms + h2d_ms) * 1e-3), 1)}
+        log(f"host->device batch copy {h2d_ms:.3f} ms ({nbytes / 1e6:.1f} MB): {h2d['value_with_serial_h2d']} utt/s if not overlapped")
+        del host, dst
+
     # north_star sub-target: the cross-attention QK^T / AV cores alone (both directions, dropout as in the step),
     # algorithmic FLOPs (fwd 4*B*H*Lq*Lk*hd, bwd 2x) over the kernels' own time, against the dense bf16 MFMA peak and
     # against the attention roofline min(MFMA peak, AI * HBM) with AI = Lq*Lk/(Lq+Lk) flop/B
@@ -373,7 +393,7 @@ def main():
                           "grad_allreduce": ("fp32 flat buckets 32MiB, RCCL, " + ("after the replay" if use_graph else "launched from gradient-ready hooks during backward")) if world > 1 else "none",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "streams": 2 if os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0" else 1},
-               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn, "ragged_masks": ragged,
+               "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn, "ragged_masks": ragged, "pcie": h2d,
                "model_tflops": round(value * FLOP_PER_UTT_FWD_BWD / 1e12, 1),
                "model_mfma_frac": round(value * FLOP_PER_UTT_FWD_BWD / 1e12 / world / PEAK_BF16_TFLOPS, 4)}
         if roof is not None:
