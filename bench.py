@@ -69,8 +69,8 @@ def cpu_model():
 
 
 def cpu_baseline():
-    """CPU oracle (fp32, train mode, dropout 0.1), same shapes: B=8 on all host cores of this GPU's share (1 warm-up + up to
-    3 timed steps), then one B=2 step on ONE thread (SURVEY 8d asks both); bounded to ~10-30 s of CPU work."""
+    """CPU oracle (fp32, train mode, dropout 0.1), same shapes: B=16 on all host cores of this GPU's share (1 warm-up + up to
+    6 timed steps), then B=2 steps on ONE thread (SURVEY 8d asks both); bounded to ~10-30 s of CPU work."""
     from oracle import hri_emo_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -102,12 +102,12 @@ def cpu_baseline():
         times.sort()
         return B / times[len(times) // 2]
 
-    v_all = timed(8, cores, 3)
-    v_one = timed(2, 1, 1)
+    v_all = timed(16, cores, 6)
+    v_one = timed(2, 1, 2)
     return {"value": round(v_all, 3), "unit": "utterances/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "one_thread_value": round(v_one, 3),
-            "sample": f"CPU oracle fp32 train-mode fwd+bwd, d=768 T_a=400 T_t=128 N_e=6: B=8 on {cores} threads, median of the timed "
-                      f"steps (<=3) after 1 warm-up; one_thread_value: B=2, 1 thread, 1 timed step after 1 warm-up"}
+            "sample": f"CPU oracle fp32 train-mode fwd+bwd, d=768 T_a=400 T_t=128 N_e=6: B=16 on {cores} threads, median of the timed "
+                      f"steps (<=6) after 1 warm-up; one_thread_value: B=2, 1 thread, median of 2 timed steps after 1 warm-up"}
 
 
 def main():
