@@ -60,6 +60,8 @@ class GradBuckets:
         self._works = []
         self._hooks = []
         if overlap and self.world > 1:
+            from . import _ops
+            _ops.grad_hooks_active = lambda: bool(self._hooks) and not self.suspended      # an overlapped exchange wants gradients in production order
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 p._hriemo_grad_ready = self._on_grad_sink     # gradients the kernels accumulate in place (_ops.GradSink)

@@ -129,6 +129,7 @@ class CrossModalTransformer(nn.Module):
     def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
         all_layers_attn = []
         plan = None
+        _ops.FLUSH_AFTER_SITE = self.layers[0]._site[1]      # layer-0 text self-attention: the last text-branch backward (_ops._DeferredWgrad)
         if _ops.varlen() and not need and mask_a is not None and mask_t is not None and _ops.precision() == "bf16":
             # the encoder on the valid rows only (prefix masks, as the collate builds them); anything else
             # takes the padded path
