@@ -133,6 +133,13 @@ def new_site_base():
 
 _seed_words = {}
 CAPTURING = False          # set by dp.DataParallelStep.capture(): weight shadows are re-cast inside the graph
+STEP_ID = 0                # bumped at the top of every model step (begin_step): "this shadow was already cast in this step"
+
+
+def begin_step():
+    global STEP_ID
+    STEP_ID += 1
+
 WEIGHTS_EPOCH = 0          # bumped by anything that rewrites parameter storage behind autograd's back (optim.FusedClipAdamW
                            # updates the flat buffer through raw pointers: p._version and p.data_ptr() do not move)
 
@@ -176,7 +183,9 @@ class Shadows:
         key = id(p)
         ent = self._d.get(key)
         ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
-        if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
+        # inside a capture every step re-casts (the replayed graph must honour optimizer updates), but only once per step:
+        # a shadow prefetched at the top of the step (prefetch()) is not cast again on the decoder's serial chain
+        if (CAPTURING and (ent is None or len(ent) < 3 or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != p.device:
             s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
                 torch.empty(p.shape, dtype=BF16, device=p.device)
             _require_gpu(p)
@@ -185,9 +194,13 @@ class Shadows:
             if not src.is_contiguous():
                 src = src.contiguous()
             _lib.call("hriemo_cast_f32_to_bf16", _p(src), _p(s), src.numel(), _stream())
-            ent = (ver, s)
+            ent = (ver, s, STEP_ID)
             self._d[key] = ent
         return ent[1]
+
+    def prefetch(self, params):
+        for p in params:
+            self.get(p)
 
 
 FUSED_WGRAD = True

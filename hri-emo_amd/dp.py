@@ -210,6 +210,7 @@ class DataParallelStep:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         _ops.CAPTURING = True
+        _ops.begin_step()
         try:
             # capture on the stream the warm-up ran on: its workspaces (keyed by stream) exist already, so nothing the
             # graph points into comes from the graph's private pool or is first sized during capture.

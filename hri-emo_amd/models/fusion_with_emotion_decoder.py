@@ -11,6 +11,10 @@ from .beta_gate_tacfn import BetaGate
 from .emotion_decoder import EmotionDecoder
 
 
+import os as _os
+_PREFETCH = _os.environ.get("HRIEMO_PREFETCH_SHADOWS", "1") != "0"
+
+
 class FusionWithEmotionDecoder(nn.Module):
     def __init__(self, d_model: int = 768, num_emotions: int = 4, n_heads: int = 8, num_layers_fusion: int = 2,
                  num_layers_decoder: int = 2, beta_hidden: int = 256, dropout: float = 0.1):
@@ -27,6 +31,27 @@ class FusionWithEmotionDecoder(nn.Module):
         for m in self.modules():
             if hasattr(m, "batch_offset"):
                 m.batch_offset = int(offset)
+
+    def _prefetch_shadows(self, device):
+        """bf16 copies of the gate's and the decoder's weights, cast on the side stream at the top of the step: on the decoder's
+        serial chain of latency-bound launches the 18 cast kernels were 90 us per step that nothing could hide (the encoder's
+        casts hide under its GEMMs).  Returns the event the consumer stream waits for, or None (one stream / fp32 mode)."""
+        if _ops.precision() != "bf16" or not device.type == "cuda" or not _PREFETCH:
+            return None
+        side = _ops.side_stream(device)
+        if side is None:
+            return None
+        main = torch.cuda.current_stream(device)
+        side.wait_stream(main)                       # the masters may have just been updated on the caller's stream
+        with torch.cuda.stream(side):
+            g = self.beta_gate
+            g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))
+            for layer in self.emotion_decoder.layers:
+                layer._sh.prefetch((layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
+                                    layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight))
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
 
     def _ensure_3d(self, x):
         if x.dim() == 2:
@@ -61,7 +86,11 @@ class FusionWithEmotionDecoder(nn.Module):
         # one cast at the boundary; between the sub-modules activations travel as (bf16, fp32-twin) pairs
         a, a32 = _ops.as_pair(h_a)
         t, t32 = _ops.as_pair(h_t)
+        _ops.begin_step()
+        ready = self._prefetch_shadows(a.device)
         a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+        if ready is not None:
+            torch.cuda.current_stream(a.device).wait_event(ready)
         h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)
         fused_mask = self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
         z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype)
