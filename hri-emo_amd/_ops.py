@@ -239,9 +239,12 @@ class GradSink:
     def ret(self, t):
         return None if self.fused else t
 
-    def done(self):
+    def done(self, skip=()):
+        """skip: parameters another Function still adds to in this backward (it reports them)"""
         if self.fused:
             for p in self.params:
+                if any(p is q for q in skip):
+                    continue
                 hook = getattr(p, "_hriemo_grad_ready", None)
                 if hook is not None:
                     if p.dim() < 2 and DEFER_REDUCE and _in_backward():
@@ -924,7 +927,9 @@ class CrossAttnLN(torch.autograd.Function):
     """y = LN(xq + drop(out_proj(MHA_core(Wq xq, Wkv xkv)))) ; returns (y, probs|None)"""
 
     @staticmethod
-    def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
+    def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w, kv_pre=None):
+        """kv_pre: the K | V projection of xkv computed by KVProjFn ahead of time (the decoder hoists it onto the side stream); its
+        weight-gradient and dX then belong to that Function, this one returns dK | dV for it"""
         if precision() == "fp32":
             _fp32().guard(ctx, "cross-attention sub-layer")
             return _fp32().cross_attn_ln(xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w)
@@ -944,10 +949,13 @@ class CrossAttnLN(torch.autograd.Function):
         xq2 = _contig_bf16(xq).view(B * Lq, d)
         xq32 = _c32(xq32)
         x32v = xq32.view(B * Lq, d) if xq32 is not None else None
-        xkv2 = _contig_bf16(xkv).view(B * Lk, d)
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         q = proj_fwd(Operand(xq2, mx_of(xq)), sh, w_in, w_in16, b_in, rows=(0, d))
-        kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
+        if kv_pre is not None:
+            xkv2, kv = None, kv_pre
+        else:
+            xkv2 = _contig_bf16(xkv).view(B * Lk, d)
+            kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
         o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd) else \
             attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
@@ -958,6 +966,7 @@ class CrossAttnLN(torch.autograd.Function):
         ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
         ctx.packed = (AB, ALq, ALk, cu)
+        ctx.kv_pre = kv_pre is not None
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
         return tag_mx(y.view(B, Lq, d), mx[0] if mx else None), (y32.view(B, Lq, d) if y32 is not None else None), probs
@@ -985,16 +994,57 @@ class CrossAttnLN(torch.autograd.Function):
                           site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits, cu=cu)
         dw_in = sink.buf(p_w_in)
         linear_dw(dq, xq2, dw_in[:d], acc)
-        linear_dw(dkv, xkv2, dw_in[d:], acc)
         if not folded:
             colsum(dq, db_in[:d], acc)
             colsum(dkv, db_in[d:], acc)
         dxq = linear_dx(dq, w_in16[:d], epi=3, aux=ds)
+        r = sink.ret
+        if ctx.kv_pre:
+            # the K | V projection belongs to KVProjFn: it gets dK | dV, adds its rows of dW_in and reports the parameter
+            if not acc:
+                dw_in[d:].zero_()
+            sink.done(skip=(p_w_in,))
+            return (dxq.view(B, Lq, d), None, None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8 + (dkv,)
+        linear_dw(dkv, xkv2, dw_in[d:], acc)
         dxkv = linear_dx(dkv, w_in16[d:])
         sink.done()
-        r = sink.ret
         return (dxq.view(B, Lq, d), None, dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
-                r(dbeta)) + (None,) * 8
+                r(dbeta)) + (None,) * 9
+
+
+class KVProjFn(torch.autograd.Function):
+    """kv[B*L_k, 2d] = x_kv . W_in[d:3d]^T + b_in[d:3d]: the key / value half of a cross-attention's packed in-projection as a node
+    of its own, so that the decoder can run it (forward and backward) on the side stream beside its serial chain of
+    latency-bound launches -- the memory does not depend on the queries (models/emotion_decoder.py:48-54).  The bias gradient
+    stays with CrossAttnLN (it comes out of the attention backward's column sums)."""
+
+    @staticmethod
+    def forward(ctx, xkv, w_in, b_in, sh):
+        _require_fp32_masters(w_in, b_in)
+        _require_gpu(xkv)
+        B, Lk, d = xkv.shape
+        xkv2 = _contig_bf16(xkv).view(B * Lk, d)
+        w_in16 = sh.get(w_in)
+        kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
+        ctx.save_for_backward(xkv2, w_in16)
+        ctx.cfg = (B, Lk, d)
+        ctx.params = (w_in,)
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        xkv2, w_in16 = ctx.saved_tensors
+        B, Lk, d = ctx.cfg
+        dkv = _contig_bf16(dkv)
+        sink = GradSink(ctx.params)
+        acc = sink.fused
+        dw_in = sink.buf(ctx.params[0])
+        if not acc:
+            dw_in[:d].zero_()
+        linear_dw(dkv, xkv2, dw_in[d:], acc)
+        dxkv = linear_dx(dkv, w_in16[d:])
+        sink.done()
+        return dxkv.view(B, Lk, d), sink.ret(dw_in), None, None
 
 
 class FFNLN(torch.autograd.Function):

@@ -17,6 +17,10 @@ def _memory16(memory):
     return m16
 
 
+import os as _os
+_HOIST_KV = _os.environ.get("HRIEMO_HOIST_KV", "1") != "0"
+
+
 class ExplainableDecoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
         super().__init__()
@@ -37,7 +41,7 @@ class ExplainableDecoderLayer(nn.Module):
         self._site = [_ops.new_site_base() for _ in range(3)]
         self.batch_offset = 0
 
-    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need):
+    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need, kv_pre=None, kv_ready=None):
         B, L, _ = memory.shape
         kpm = _ops.mask_u8(memory_key_padding_mask, B, L)
         p = self.p if self.training else 0.0
@@ -46,10 +50,12 @@ class ExplainableDecoderLayer(nn.Module):
         tgt, tgt32, _ = _ops.SelfAttnLN.apply(tgt, tgt32, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
                                               sa.out_proj.bias, self.norm1.weight, self.norm1.bias, self._sh,
                                               self.nhead, None, p, seed, s[0], self.batch_offset, False)     # :42-43
+        if kv_ready is not None:          # K | V of the memory were projected on the side stream (EmotionDecoder._fwd)
+            torch.cuda.current_stream(memory.device).wait_event(kv_ready)
         tgt, tgt32, w = _ops.CrossAttnLN.apply(tgt, tgt32, memory, ca.in_proj_weight, ca.in_proj_bias,
                                                ca.out_proj.weight, ca.out_proj.bias, self.norm2.weight,
                                                self.norm2.bias, self._sh, self.nhead, kpm, p, seed, s[1],
-                                               self.batch_offset, need)                                       # :48-55
+                                               self.batch_offset, need, kv_pre)                               # :48-55
         tgt, tgt32 = _ops.FFNLN.apply(tgt, tgt32, self.linear1.weight, self.linear1.bias, self.linear2.weight,
                                       self.linear2.bias, self.norm3.weight, self.norm3.bias, self._sh, p, p, seed,
                                       s[2], self.batch_offset)                                                # :58-59
@@ -90,8 +96,24 @@ class EmotionDecoder(nn.Module):
         if _ops.precision() == "fp32":
             from hri_emo_amd import _fp32
             memory16 = _fp32.f32_of(memory16)          # the layers read the fp32 values of the memory (h_fusion's twin)
-        for layer in self.layers:
-            out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need)
+        # The memory's K | V projections (one [B*L_f, 2d] GEMM per layer, the only chip-sized launches of the decoder) do not depend
+        # on the queries: all layers' are issued up front on the side stream and run -- forward and, through autograd, backward --
+        # beside the decoder's serial chain of M = B*N_e launches instead of inside it.
+        kvs, ready = [None] * len(self.layers), None
+        side = _ops.side_stream(memory16.device) if (_HOIST_KV and _ops.precision() == "bf16" and memory16.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream(memory16.device)
+            side.wait_stream(main)
+            _ops.share(memory16, side)
+            with torch.cuda.stream(side):
+                kvs = [_ops.KVProjFn.apply(memory16, l.cross_attn.in_proj_weight, l.cross_attn.in_proj_bias, l._sh) for l in self.layers]
+                ready = torch.cuda.Event()
+                ready.record(side)
+            for kv in kvs:
+                _ops.share(kv, main)
+        for i, layer in enumerate(self.layers):
+            out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need, kvs[i],
+                                                   ready if i == 0 else None)
             if need and attn_map is not None:
                 all_layers_attn.append(attn_map)
         logits = None
