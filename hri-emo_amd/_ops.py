@@ -927,7 +927,8 @@ class CrossAttnLN(torch.autograd.Function):
     """y = LN(xq + drop(out_proj(MHA_core(Wq xq, Wkv xkv)))) ; returns (y, probs|None)"""
 
     @staticmethod
-    def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w, kv_pre=None):
+    def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w, kv_pre=None,
+                join_q=None):
         """kv_pre: the K | V projection of xkv computed by KVProjFn ahead of time (the decoder hoists it onto the side stream); its
         weight-gradient and dX then belong to that Function, this one returns dK | dV for it"""
         if precision() == "fp32":
@@ -967,6 +968,7 @@ class CrossAttnLN(torch.autograd.Function):
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
         ctx.packed = (AB, ALq, ALk, cu)
         ctx.kv_pre = kv_pre is not None
+        ctx.join_q = join_q
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
         return tag_mx(y.view(B, Lq, d), mx[0] if mx else None), (y32.view(B, Lq, d) if y32 is not None else None), probs
@@ -998,18 +1000,73 @@ class CrossAttnLN(torch.autograd.Function):
             colsum(dq, db_in[:d], acc)
             colsum(dkv, db_in[d:], acc)
         dxq = linear_dx(dq, w_in16[:d], epi=3, aux=ds)
+        if ctx.join_q is not None:            # xq has another consumer (GradJoin): deposit for it, or finish the sum if it came first
+            last, dep = ctx.join_q.arrive()
+            if dep is not None:
+                dxq = dxq + dep.view(B * Lq, d)          # this GEMM's aux slot carries the residual gradient: explicit add
+            if not last:
+                ctx.join_q.deposit(dxq)
+                dxq = None
+        dxq = dxq.view(B, Lq, d) if dxq is not None else None
         r = sink.ret
         if ctx.kv_pre:
             # the K | V projection belongs to KVProjFn: it gets dK | dV, adds its rows of dW_in and reports the parameter
             if not acc:
                 dw_in[d:].zero_()
             sink.done(skip=(p_w_in,))
-            return (dxq.view(B, Lq, d), None, None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8 + (dkv,)
+            return (dxq, None, None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8 + (dkv, None)
         linear_dw(dkv, xkv2, dw_in[d:], acc)
         dxkv = linear_dx(dkv, w_in16[d:])
         sink.done()
-        return (dxq.view(B, Lq, d), None, dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
-                r(dbeta)) + (None,) * 9
+        return (dxq, None, dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
+                r(dbeta)) + (None,) * 10
+
+
+class GradJoin:
+    """One tensor, n consumers that are Functions of this file (the audio self-attention output feeds the a2t queries AND the t2a
+    keys / values; the decoder's memory feeds every layer): autograd would sum their gradients with an elementwise add launch per
+    pair.  Here every consumer but the last DEPOSITS its gradient and returns None, the last folds the deposit into its dX
+    GEMM's add-aux epilogue (epi = 3) and returns the total.  "Last" is decided by arrival, so any execution order of the
+    consumers' backward is correct; a consumer that cannot fold (its GEMM's aux slot is taken) adds explicitly.  If a consumer's
+    backward never runs, the deposit would be lost: an engine final callback checks that every join was completed."""
+
+    def __init__(self, n=2):
+        self.n, self.seen, self.dep, self.ev = n, 0, None, None
+
+    def arrive(self):
+        """-> (is_last, deposit | None): the deposit is ordered before the caller's stream on return"""
+        if self.seen == 0:
+            torch.autograd.Variable._execution_engine.queue_callback(self._check)
+        self.seen += 1
+        last = self.seen == self.n
+        dep, ev = self.dep, self.ev
+        self.dep = self.ev = None
+        if last:
+            self.seen = 0
+        if dep is not None:
+            cur = torch.cuda.current_stream(dep.device)
+            if ev != cur:                      # `ev` is the depositor's stream
+                cur.wait_stream(ev)
+                if not CAPTURING:
+                    dep.record_stream(cur)
+        return last, dep
+
+    def deposit(self, t):
+        self.dep = t
+        self.ev = torch.cuda.current_stream(t.device)
+
+    def _check(self):
+        if self.seen != 0 or self.dep is not None:
+            self.seen, self.dep, self.ev = 0, None, None
+            raise RuntimeError("GradJoin: a consumer of a shared activation did not run its backward; its partner's gradient was "
+                               "deposited for it (set HRIEMO_GRAD_JOIN=0 to let autograd sum the gradients)")
+
+
+GRAD_JOIN = _os.environ.get("HRIEMO_GRAD_JOIN", "1") != "0"
+
+
+def grad_join(n=2):
+    return GradJoin(n) if (GRAD_JOIN and torch.is_grad_enabled()) else None
 
 
 class KVProjFn(torch.autograd.Function):
@@ -1019,9 +1076,10 @@ class KVProjFn(torch.autograd.Function):
     stays with CrossAttnLN (it comes out of the attention backward's column sums)."""
 
     @staticmethod
-    def forward(ctx, xkv, w_in, b_in, sh):
+    def forward(ctx, xkv, w_in, b_in, sh, join=None):
         _require_fp32_masters(w_in, b_in)
         _require_gpu(xkv)
+        ctx.join = join
         B, Lk, d = xkv.shape
         xkv2 = _contig_bf16(xkv).view(B * Lk, d)
         w_in16 = sh.get(w_in)
@@ -1042,9 +1100,13 @@ class KVProjFn(torch.autograd.Function):
         if not acc:
             dw_in[:d].zero_()
         linear_dw(dkv, xkv2, dw_in[d:], acc)
-        dxkv = linear_dx(dkv, w_in16[d:])
+        last, dep = ctx.join.arrive() if ctx.join is not None else (True, None)
+        dxkv = linear_dx(dkv, w_in16[d:], epi=3, aux=dep.view(B * Lk, d)) if dep is not None else linear_dx(dkv, w_in16[d:])
         sink.done()
-        return dxkv.view(B, Lk, d), sink.ret(dw_in), None, None
+        if not last:
+            ctx.join.deposit(dxkv)
+            return None, sink.ret(dw_in), None, None, None
+        return dxkv.view(B, Lk, d), sink.ret(dw_in), None, None, None
 
 
 class FFNLN(torch.autograd.Function):

@@ -42,10 +42,15 @@ class CrossModalBlock(nn.Module):
                                      mha.out_proj.bias, ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed, site,
                                      self.batch_offset, need_w)
 
-    def _cross(self, xq, xq32, xkv, mha, ln, kpm, p, seed, site, need_w):
+    def _cross(self, xq, xq32, xkv, mha, ln, kpm, p, seed, site, need_w, kv_pre=None, join_q=None):
         return _ops.CrossAttnLN.apply(xq, xq32, xkv, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                                       mha.out_proj.bias, ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed,
-                                      site, self.batch_offset, need_w)
+                                      site, self.batch_offset, need_w, kv_pre, join_q)
+
+    def _kv(self, xkv, mha, join):
+        """K | V projection of a cross-attention as its own node (_ops.KVProjFn): the gradient it returns for `xkv` meets the
+        gradient the OTHER cross-attention returns for the same tensor as its query side in a GradJoin"""
+        return _ops.KVProjFn.apply(xkv, mha.in_proj_weight, mha.in_proj_bias, self._sh, join)
 
     def _ffn(self, x, x32, ffn, ln, p, seed, site):
         return _ops.FFNLN.apply(x, x32, ffn[0].weight, ffn[0].bias, ffn[2].weight, ffn[2].bias, ln.weight, ln.bias,
@@ -73,12 +78,24 @@ class CrossModalBlock(nn.Module):
         main = torch.cuda.current_stream(a.device)
         _ops.note_main_stream(main)
         side = _ops.side_stream(a.device)
+        # Each self-attention output has two consumers -- the queries of its own cross-attention and the keys / values of the
+        # other one.  With the K | V projections as their own nodes, created BEFORE both cross-attention cores, the engine runs
+        # the cores' backward first (they deposit the query-side gradients) and the projections' backward last, where one
+        # dX GEMM adds the deposit in its epilogue: no elementwise add launches on [B*L, d] (_ops.GradJoin).
+        ja = jt = None
+        use_kv = not fp32
+        if use_kv:
+            ja, jt = _ops.grad_join(2), _ops.grad_join(2)
         if side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
             t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
-            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need)  # :98-105
+            kv_t2a = self._kv(a_s, self.attn_t2a, ja) if use_kv else None
+            kv_a2t = self._kv(t_s, self.attn_a2t, jt) if use_kv else None
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
+                                        kv_a2t, ja)                                                                # :98-105
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
-            x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need)  # :111-118
+            x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
+                                        kv_t2a, jt)                                                                # :111-118
             t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
         else:
             # The audio and text branches only meet at the two cross-attentions (each reads the OTHER branch's
@@ -99,10 +116,17 @@ class CrossModalBlock(nn.Module):
             if fp32:
                 _ops.share(t_s32, main)
                 _ops.share(a_s32, side)
+            kv_t2a = kv_a2t = None
+            if use_kv:
+                with torch.cuda.stream(side):
+                    kv_t2a = self._kv(a_s, self.attn_t2a, ja)
+                kv_a2t = self._kv(t_s, self.attn_a2t, jt)
             with torch.cuda.stream(side):
-                x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need)
+                x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
+                                            kv_t2a, jt)
                 t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])
-            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need)
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
+                                        kv_a2t, ja)
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])
             main.wait_stream(side)
             for x_ in (t_cm, t_cm32, w_t, w_t2a):

@@ -655,6 +655,36 @@ def test_eager_steps_with_fused_optimizer_follow_torch_adamw(H):
     close(o1[0], o2[0], 2e-2, "logits after 4 steps")
 
 
+def test_shared_activation_gradients_joined_in_the_gemm_epilogue(H, monkeypatch):
+    """_ops.GradJoin: the two consumers of each self-attention output (and the decoder layers' shared memory) hand their gradients
+    to ONE dX GEMM instead of an autograd add launch.  Same gradients as with autograd summing them (HRIEMO_GRAD_JOIN=0 path), to
+    one bf16 rounding of the summed activation gradient; and a join whose partner never ran must raise, not lose a gradient."""
+    from hri_emo_amd import _ops
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(5)
+    kw = dict(d_model=256, num_emotions=5, n_heads=8, dropout=0.0)
+    m = H.FusionWithEmotionDecoder(**kw).cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(4, 90, 36, 256, 23)
+    y = (torch.rand(4, 5, generator=torch.Generator().manual_seed(2)) < 0.3).float().cuda()
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "GRAD_JOIN", on)
+        m.zero_grad(set_to_none=True)
+        logits, beta, z = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+        fusion_step_loss(logits, beta, y).backward()
+        grads.append({n: p.grad.detach().float().clone() for n, p in m.named_parameters()})
+    worst = max(float((grads[0][n] - grads[1][n]).norm() / grads[1][n].norm().clamp_min(1e-20)) for n in grads[0])
+    assert worst <= 1e-2, worst              # the joined path rounds (g1 + g2) once, autograd rounds g1, g2 and their sum
+    monkeypatch.setattr(_ops, "GRAD_JOIN", True)
+    j = _ops.GradJoin(2)
+    x = torch.randn(2, 8, 128, device="cuda", requires_grad=True)
+    w = torch.nn.Parameter(torch.randn(384, 128, device="cuda") * 0.05)
+    b = torch.nn.Parameter(torch.zeros(384, device="cuda"))
+    kv = _ops.KVProjFn.apply(x, w, b, _ops.Shadows(), j)
+    with pytest.raises(RuntimeError, match="GradJoin"):
+        kv.float().sum().backward()          # the join's other consumer never arrives
+
+
 def test_trimmed_batch_gives_the_same_outputs(H):
     """dropping the columns that are PAD for every sample (data.trim_padding) must not change what
     the model returns -- PAD keys are masked, PAD query rows feed nothing."""
