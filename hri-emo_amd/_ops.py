@@ -680,6 +680,7 @@ _deferred = _DeferredReduce()
 # autograd-engine final callback if no such point comes.  Measured at cfg 2: 8.87 -> 8.7 ms per step (skipping them altogether:
 # 8.65).  Off while gradient-ready hooks drive an overlapped exchange (the decoder's bucket would leave last instead of first);
 # HRIEMO_DEFER_SMALL_DW=0 disables it.
+GATE_TWO_STREAMS = _os.environ.get("HRIEMO_GATE_TWO_STREAMS", "1") != "0"     # the gate's text-side LayerNorm + pooling on the side stream
 DEFER_SMALL_DW = _os.environ.get("HRIEMO_DEFER_SMALL_DW", "1") != "0"
 SMALL_DW_ROWS = 1024
 FLUSH_AFTER_SITE = None            # dropout-site id of the sub-layer whose backward ends the text branch (set by CrossModalTransformer)
@@ -1196,10 +1197,25 @@ class BetaGateFn(torch.autograd.Function):
         mean_t, rstd_t = torch.empty(B * Lt, **f32), torch.empty(B * Lt, **f32)
         pa, pt = torch.empty((B, nca, d), **f32), torch.empty((B, nct, d), **f32)
         st = _stream()
-        _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(h_a32), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa),
-                  B, La, L, d, _EPS, st)
-        _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt),
-                  B, Lt, L, d, _EPS, st)
+        # the two modalities' LayerNorm + pooling are independent: the (small) text one runs on the side stream beside the audio one
+        main = torch.cuda.current_stream(dev)
+        side = side_stream(dev) if GATE_TWO_STREAMS else None
+        if side is not None and side != main:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt),
+                          B, Lt, L, d, _EPS, _stream())
+            _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(h_a32), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa),
+                      B, La, L, d, _EPS, st)
+            main.wait_stream(side)
+            if not CAPTURING:
+                for t_ in (xt, h_t32, kpm_t, Tn, mean_t, rstd_t, pt):
+                    share(t_, side)
+        else:
+            _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(h_a32), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa),
+                      B, La, L, d, _EPS, st)
+            _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt),
+                      B, Lt, L, d, _EPS, st)
         gin = torch.empty((B, 4 * d), dtype=BF16, device=dev)
         a_pool, t_pool = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
         cnt = torch.empty((B, 2), **f32)
@@ -1251,10 +1267,26 @@ class BetaGateFn(torch.autograd.Function):
         sa, st_ = torch.empty((2, d), **f32), torch.empty((2, d), **f32)
         ws = workspace(max(L_.hriemo_ln_pool_bwd_workspace_bytes(B, La, d),
                            L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d)), dev, slot=1)
-        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a),
-                  _p(rstd_a), _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
-        _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
-                  _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
+        main = torch.cuda.current_stream(dev)
+        side = side_stream(dev) if GATE_TWO_STREAMS else None
+        if side is not None and side != main:
+            # text on the side stream (its own workspace there), audio on this one; joined before the gradients are handed back
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ws_t = workspace(L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d), dev, slot=1)
+                _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
+                          _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws_t), _stream())
+            _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a),
+                      _p(rstd_a), _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
+            main.wait_stream(side)
+            if not CAPTURING:
+                for t_ in (dH2, w, dt, dxt, st_):
+                    share(t_, side)
+        else:
+            _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a),
+                      _p(rstd_a), _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
+            _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
+                      _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
         return dxa, None, dxt, None, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
 
 
