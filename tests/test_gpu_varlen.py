@@ -172,6 +172,31 @@ def test_train_step_gradients_varlen_vs_padded(H):
     print(f"packed vs padded gradients: worst relative L2 difference {worst:.2e}; valid fraction audio {float(la.sum()) / (B * Ta):.2f} text {float(lt.sum()) / (B * Tt):.2f}")
 
 
+def test_train_step_with_dropout_runs_packed(H):
+    """dropout on: the attention masks are keyed by position within the sequence (identical packed / padded, checked at kernel
+    level above), the LayerNorm / FFN masks by row, which packing renumbers -- so the two steps are different draws of the same
+    model: finite, and close in loss"""
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=5, n_heads=8, dropout=0.1).cuda().train()
+    g = torch.Generator().manual_seed(4)
+    B, Ta, Tt, d = 8, 120, 48, 256
+    h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda(), torch.randn(B, Tt, d, generator=g).cuda()
+    la = torch.randint(30, Ta + 1, (B,), generator=g); lt = torch.randint(10, Tt + 1, (B,), generator=g)
+    m_a, m_t = (torch.arange(Ta)[None] >= la[:, None]).cuda(), (torch.arange(Tt)[None] >= lt[:, None]).cuda()
+    y = (torch.rand(B, 5, generator=g) < 0.3).float().cuda()
+    losses = []
+    for packed in (False, True):
+        H.set_varlen(packed)
+        m.zero_grad(set_to_none=True)
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+        loss = fusion_step_loss(logits, beta, y)
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        losses.append(float(loss))
+    assert abs(losses[0] - losses[1]) < 0.1 * max(1.0, abs(losses[0])), losses
+
+
 def test_captured_step_refuses_other_masks_in_packed_mode(H):
     from hri_emo_amd.dp import DataParallelStep
     from hri_emo_amd.train import fusion_step_loss
