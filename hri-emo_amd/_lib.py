@@ -13,6 +13,8 @@ _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 _SIGS = {
     "hriemo_gemm_bf16": ("iiiiiplplplipipliplp", "i"),
     "hriemo_gemm_force_config": ("i", "i"),
+    "hriemo_gemm_colsum_rows": ("iiiii", "i"),
+    "hriemo_gemm_bf16_colsum": ("iiiiiplplplplpp", "i"),
     "hriemo_mx8_scale_ld": ("i", "l"),
     "hriemo_quant_mx8": ("pliiiplplp", "i"),
     "hriemo_gemm_mx8": ("iiiplplplplplipiplp", "i"),

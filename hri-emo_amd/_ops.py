@@ -310,6 +310,36 @@ def linear_dx(dy, w16, epi=0, aux=None):
     return dx
 
 
+FOLD_FFN_BIAS = None
+
+
+def fold_ffn_bias():
+    global FOLD_FFN_BIAS
+    if FOLD_FFN_BIAS is None:
+        FOLD_FFN_BIAS = _os.environ.get("HRIEMO_FOLD_FFN_BIAS", "1") != "0"
+    return FOLD_FFN_BIAS
+
+
+def linear_dx_masked_colsum(dy, w16, aux, bias_out, accumulate):
+    """dX[M,K] = (dY . W) * (aux > 0) and bias_out[K] (+)= colsum(dX) in one pass: the GEMM's epilogue leaves per-row-block
+    partial sums of the tile it stores, finished by the launch-boundary reduce inside backward (fused path) or right here"""
+    M, N = dy.shape
+    K = w16.shape[1]
+    dx = torch.empty((M, K), dtype=BF16, device=dy.device)
+    rows = _lib.lib().hriemo_gemm_colsum_rows(0, 1, M, K, N)
+    part = torch.empty(rows * K, dtype=torch.float32, device=dy.device)
+    _lib.call("hriemo_gemm_bf16_colsum", 0, 1, M, K, N, _p(dy), dy.stride(0), _p(w16), w16.stride(0), _p(dx), K, _p(aux), aux.stride(0),
+              _p(part), _stream())
+    if accumulate and DEFER_REDUCE and _in_backward():
+        _deferred.add(part, K, rows, K, 1, [bias_out], True)
+    else:
+        red = _DeferredReduce()
+        red.device = dy.device
+        red.add(part, K, rows, K, 1, [bias_out], accumulate, schedule=False)
+        red.flush()
+    return dx
+
+
 def linear_dw(dy, x, out, accumulate=False):
     """out[N,K] (fp32, row stride free) (+)= dY[M,N]^T . X[M,K]"""
     M, N = dy.shape
@@ -1156,14 +1186,19 @@ class FFNLN(torch.autograd.Function):
                                                 accumulate=acc, x32=x32v)
         dw2 = sink.buf(p_w2)
         linear_dw(dg, hd_, dw2, acc)
-        da = linear_dx(dg, w2_16, epi=2, aux=h)          # * relu'(h)
+        db1 = sink.buf(p_b1)
+        fold = p_mid == 0 and fold_ffn_bias()
+        if fold:                                         # db1 = colsum(da) out of the GEMM that writes da
+            da = linear_dx_masked_colsum(dg, w2_16, h, db1, acc)
+        else:
+            da = linear_dx(dg, w2_16, epi=2, aux=h)          # * relu'(h)
         if p_mid > 0:
             _lib.call("hriemo_dropout_bf16", _p(da), _p(da), M, F, float(p_mid), seed, _p(seed_word(dev)), site + 2, b_off * L,
                       _stream())
         dw1 = sink.buf(p_w1)
         linear_dw(da, x2, dw1, acc)
-        db1 = sink.buf(p_b1)
-        colsum(da, db1, acc)
+        if not fold:
+            colsum(da, db1, acc)
         dx = linear_dx(da, w1_16, epi=3, aux=ds)
         sink.done()
         r = sink.ret

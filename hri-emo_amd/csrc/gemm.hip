@@ -546,9 +546,24 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
   return (N >= 2048 && M >= 16384) ? 2 : 1;                                    // NN
 }
 
-extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
-                                void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
-                                long ldaux, int accumulate, float* workspace, long workspace_bytes, hipStream_t st) {
+// rows of the column-sum partials of hriemo_gemm_bf16_colsum: one per wave row-block of the tile configuration the launch takes
+static int wave_rows(int cfg) {
+  static const int waves_m[] = {2, 4, 2, 2, 2, 4};
+  return kCfg[cfg].bm / waves_m[cfg];
+}
+static int pick_config(int ta, int tb, int M, int N, int K);
+extern "C" int hriemo_gemm_colsum_rows(int ta, int tb, int M, int N, int K) {
+  int cfg = pick_config(ta, tb, M, N, K);
+  if (cfg == 3 && ta == 1) cfg = 0;
+  if (cfg == 5 && ta == 1) cfg = 0;
+  if (K <= (kCfg[cfg].ns - 2) * kCfg[cfg].bk) cfg = 0;
+  const int wr = wave_rows(cfg);
+  return (M + wr - 1) / wr;
+}
+
+static int gemm_impl(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                     void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
+                     long ldaux, int accumulate, float* workspace, long workspace_bytes, float* colsum_partials, hipStream_t st) {
   HRIEMO_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   HRIEMO_CHECK(!(ta == 1 && tb == 0), "gemm: layout (ta=1,tb=0) is not used by this path and not built");
   HRIEMO_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
@@ -571,6 +586,8 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   a.C = C; a.ldc = ldc; a.bias = bias; a.aux = (const bf16_t*)aux; a.ldaux = ldaux; a.epi = epilogue;
   a.tiles_m = (M + kCfg[cfg].bm - 1) / kCfg[cfg].bm; a.tiles_n = (N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   a.ws = workspace; a.accumulate = accumulate; a.sched = nullptr;
+  a.cs = colsum_partials;
+  HRIEMO_CHECK(colsum_partials == nullptr || (epilogue == 2 && !c_is_f32), "gemm: column sums are built for the masked epilogue (2) with bf16 output");
   int splitk = 1;
   if (c_is_f32) {
     const long tiles = (long)a.tiles_m * a.tiles_n;
@@ -611,4 +628,16 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
   }
   hriemo_prof_end(cls, st, 2.0 * M * N * K);
   return 0;
+}
+
+extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                                void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
+                                long ldaux, int accumulate, float* workspace, long workspace_bytes, hipStream_t st) {
+  return gemm_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux, ldaux, accumulate, workspace, workspace_bytes,
+                   nullptr, st);
+}
+extern "C" int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                                       void* C, long ldc, const void* aux, long ldaux, float* colsum_partials, hipStream_t st) {
+  HRIEMO_CHECK(colsum_partials != nullptr, "gemm_colsum: partials buffer missing");
+  return gemm_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 0, nullptr, 2, aux, ldaux, 0, nullptr, 0, colsum_partials, st);
 }

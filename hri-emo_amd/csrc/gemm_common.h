@@ -17,6 +17,9 @@ struct GemmArgs {
   float* ws;
   int accumulate;
   unsigned* sched;   // per-launch work queue: [0..7] per-XCD next-unit counters, [8] blocks finished; nullptr = static walk
+  // optional column sums of the stored tile (EPI 2 only: the ReLU-masked dX of an FFN, whose column sums are the first Linear's
+  // bias gradient): one fp32 partial row per wave row-block, [ceil(M / (wave tile rows))][N]; nullptr = none
+  float* cs;
   // MX-fp8 operands only (gemm_mx8.hip): E8M0 block scales, one byte per 32 k-elements, laid out [K/32][ld] (k-block major)
   const uint8_t* SA; long ldsa;
   const uint8_t* SB; long ldsb;
@@ -256,6 +259,9 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
     const int wsw = i & 7, gh = g >> 1;
     const char* rd0 = scratch + rr * 128 + ((cc ^ rr) << 4);          // rows rr and rr+8 share row&7
     if (EPI >= 2) load_chunk(0, 0);
+    float cs8[EPI == 2 ? 8 : 1];          // EPI 2: running column sums of this lane's 16-byte line position (8 columns), fp32
+#pragma unroll
+    for (int e = 0; e < (EPI == 2 ? 8 : 1); ++e) cs8[e] = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (EPI >= 2 && c + 1 < NCH) load_chunk(c + 1, (c + 1) & 1);
@@ -294,12 +300,33 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
             // pin the masked line HERE: sunk into the predicated store below, the aux load would stay unretired on
             // the not-taken path and hipcc would guard every fragment register of the K loop with s_waitcnt vmcnt
             asm volatile("" : "+v"(v));
+            if (p.cs != nullptr) {           // rows / columns outside the matrix were masked to zero by the range-checked aux load
+              const bf16x8 m8 = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) cs8[e] += (float)m8[e];
+            }
           }
           const bool ok = mi * 16 + k * 8 + rr < rows_valid && cc * 8 < cols_valid;
           // plain global store, uniform base + per-lane 32-bit offset.  (A raw-buffer store with the same
           // offsets loses lanes on this path, nondeterministically, on 8-wave blocks; measured, not understood.)
           if (full || ok) *(u32x4*)(cbase + (long)((mi * 16 + k * 8) * p.ldc * 2) + line_c) = v;
         }
+      }
+    }
+    if (EPI == 2 && p.cs != nullptr) {
+      // lanes rr = 0..7 hold the same 8 columns (cc): fold them (lane = rr * 8 + cc -> xor 8, 16, 32), lane rr == 0 stores
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = cs8[e];
+        t += __shfl_xor(t, 8);
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        cs8[e] = t;
+      }
+      if (rr == 0 && mb < p.M && cc * 8 < cols_valid) {
+        float* row = p.cs + (long)(mb / (MT * 16)) * p.N + nb + cc * 8;
+        *(f32x4*)row = (f32x4){cs8[0], cs8[1], cs8[2], cs8[3]};
+        *(f32x4*)(row + 4) = (f32x4){cs8[4], cs8[5], cs8[6], cs8[7]};
       }
     }
   }

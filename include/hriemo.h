@@ -44,6 +44,13 @@ int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long ld
                      void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
                      long ldaux, int accumulate, float* workspace, long workspace_bytes, hriemo_stream_t stream);
 
+/* C[M,N] (bf16) = (A . B) * (aux > 0) as hriemo_gemm_bf16 with epilogue 2, plus the column sums of the stored (masked, rounded)
+ * C as per-row-block partials [hriemo_gemm_colsum_rows(ta,tb,M,N,K)][N] fp32 -- summed over rows (hriemo_colreduce_batch) they
+ * are the bias gradient of the FIRST Linear of a feed-forward block (dh = (dy . W2) * relu'(h), db1 = colsum(dh);
+ * cross_modal_block_tacfn.py:43-52,106,119) without a second pass over dh. */
+int hriemo_gemm_colsum_rows(int ta, int tb, int M, int N, int K);
+int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                            const void* aux, long ldaux, float* colsum_partials, hriemo_stream_t stream);
 /* tuning hook: force one of the built tile configurations (-1 = built-in heuristic) */
 int hriemo_gemm_force_config(int cfg);
 

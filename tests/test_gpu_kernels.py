@@ -102,6 +102,28 @@ def test_gemm_tn_splitk_weight_gradient_shapes(ops, M, N, K):
     assert float((r1 - want).abs().max()) <= 2e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (1000, 768, 256), (25600, 3072, 768), (8192, 3072, 768), (384, 2048, 768)])
+def test_gemm_masked_dx_with_column_sums(ops, cfg, M, N, K):
+    """dX = (dY . W) * (aux > 0) with the column sums of the stored tile out of the same launch (FFN1 bias gradient): dX exact on
+    integers, column sums exact (they are sums of the rounded, masked values), every tile configuration, ragged edges"""
+    from hri_emo_amd import _lib
+    L = _lib.lib()
+    if cfg >= 0 and M * K > 4e7:
+        pytest.skip("forced configurations on the small shapes only")
+    L.hriemo_gemm_force_config(cfg)
+    try:
+        dY, W, aux = ints((M, K), -2, 3, seed=31), ints((K, N), -2, 3, seed=32), ints((M, N), -3, 4, seed=33)
+        ref = (dY @ W) * (aux > 0)
+        out = torch.full((N,), 5.0, device="cuda")
+        dx = ops.linear_dx_masked_colsum(dY.cuda().bfloat16(), W.cuda().bfloat16(), aux.cuda().bfloat16(), out, True)
+        assert torch.equal(dx.float().cpu(), ref.bfloat16().float()), (cfg, "dX")
+        want = ref.bfloat16().float().double().sum(0) + 5.0
+        assert float((out.double().cpu() - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), (cfg, "column sums")
+    finally:
+        L.hriemo_gemm_force_config(-1)
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_gemm_every_tile_config_and_persistent_walk(ops, cfg):
     """Each tile configuration forced in turn: ragged edges, every epilogue, and a problem with more tiles than
