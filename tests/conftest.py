@@ -23,3 +23,15 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def cfg2_seeded_inputs(g):
+    """inputs of tests/golden/cfg2_seeded.npz (the headline shape, B=2): regenerated from the generator seed make_golden.py used,
+    verified against the stored probes -- the fixture holds no inputs"""
+    B, Ta, Tt, d = 2, 400, 128, 768
+    gen = torch.Generator().manual_seed(21)
+    h_a = torch.randn(B, Ta, d, generator=gen)
+    h_t = torch.randn(B, Tt, d, generator=gen)
+    probe = torch.cat([h_a[0, 0, :8], h_t[1, -1, -8:], h_a.sum().reshape(1), h_t.sum().reshape(1)])
+    assert torch.allclose(probe, g["probe"], rtol=1e-6, atol=1e-4), "the seeded generator no longer reproduces the fixture's inputs"
+    return h_a, h_t, g["mask_a"], g["mask_t"]

@@ -154,6 +154,30 @@ def fusion_cases():
         loss=loss.reshape(1), g_h_a=h_a.grad, g_h_t=h_t.grad, **grad_record(m768))
 
 
+def cfg2_seeded_case():
+    """The headline shape itself (BASELINE.json configs[1]: d=768, T_a=400, T_t=128, N_e=6, H=8), B=2, ragged masks.  The inputs
+    are NOT stored (1.6 MB of noise): the tests regenerate them from the same seeded generator and check the stored probes
+    (first values, sums) before using them; outputs, loss and the gradient record are stored."""
+    cfg = dict(d_model=768, num_emotions=6, n_heads=8)
+    B, Ta, Tt, d = 2, 400, 128, 768
+    m = closed_form_init_(FusionWithEmotionDecoder(dropout=0.0, **cfg)).eval()
+    h_a, h_t, m_a, m_t = inputs(21, B, Ta, Tt, d, True)
+    probe = torch.cat([h_a[0, 0, :8], h_t[1, -1, -8:], h_a.sum().reshape(1), h_t.sum().reshape(1)])
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+    m.train()
+    y = (torch.rand(B, 6, generator=torch.Generator().manual_seed(22)) < 0.3).float()
+    h_a.requires_grad_(True)
+    h_t.requires_grad_(True)
+    lt, bt, zt = m(h_a, h_t, m_a, m_t)
+    loss = train_step_loss(lt, bt, y)
+    loss.backward()
+    npz("cfg2_seeded", probe=probe, mask_a=m_a, mask_t=m_t, y=y, logits=logits, beta=beta, z=z, loss=loss.reshape(1),
+        g_h_a_norm=h_a.grad.norm().reshape(1), g_h_t_norm=h_t.grad.norm().reshape(1),
+        g_h_a_samp=h_a.grad.reshape(-1)[torch.linspace(0, h_a.numel() - 1, 256).long()],
+        g_h_t_samp=h_t.grad.reshape(-1)[torch.linspace(0, h_t.numel() - 1, 256).long()], **grad_record(m))
+
+
 def component_cases():
     d, H, B = 128, 8, 4
     # CrossModalBlock alone (a1-a5)
@@ -275,7 +299,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "legacy_gate":      # add this fixture without rewriting the others
         legacy_gate_case()
         sys.exit(0)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "cfg2_seeded":
+        cfg2_seeded_case()
+        sys.exit(0)
     fusion_cases()
+    cfg2_seeded_case()
     component_cases()
     mosei_case()
     legacy_cases()

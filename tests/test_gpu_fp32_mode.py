@@ -173,6 +173,17 @@ def test_fusion_attention_maps_vs_golden_fp32(H, name, d, ne):
     close(w.sum(-1), torch.ones(w.shape[:-1]), 1e-5, "rows sum to one")
 
 
+def test_cfg2_shape_vs_reference_golden_fp32(H):
+    from conftest import cfg2_seeded_inputs
+    g = load_golden("cfg2_seeded")
+    h_a, h_t, m_a, m_t = cfg2_seeded_inputs(g)
+    m = fusion(H, 768, 6, p=0.0).eval()
+    with torch.no_grad():
+        logits, beta, z = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    e = [close(logits, g["logits"], what="logits"), close(beta, g["beta"], what="beta"), close(z, g["z"], what="z")]
+    print(f"cfg-2 shape vs the reference golden, fp32 mode: logits {e[0]:.2e} beta {e[1]:.2e} z {e[2]:.2e}")
+
+
 def test_fusion_allpad_row_nan_only_for_that_sample_fp32(H):
     g = load_golden("cfg1_eval_allpad_row")
     m = fusion(H, 128, 4).eval()

@@ -232,6 +232,36 @@ def test_fusion_train_step_grads_cfg2_shape(H):
     assert _rel(gt_m, gt_r) <= max(3e-2, 1.5 * _rel(gt_y, gt_r)), "d loss / d h_t"
 
 
+def test_cfg2_shape_vs_reference_golden(H):
+    """the HIP path at the headline shape (d=768, T_a=400, T_t=128, N_e=6; B=2, ragged masks) against outputs, loss and gradient
+    record generated from the reference itself (tests/golden/cfg2_seeded.npz; inputs regenerated from the seed)"""
+    from conftest import cfg2_seeded_inputs
+    g = load_golden("cfg2_seeded")
+    h_a, h_t, m_a, m_t = cfg2_seeded_inputs(g)
+    m = fusion(H, 768, 6, p=0.0).eval()
+    with torch.no_grad():
+        logits, beta, z = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    close(logits, g["logits"], what="logits"); close(beta, g["beta"], what="beta"); close(z, g["z"], what="z")
+    # gradients: the fp32 oracle on the same (closed-form) weights is first tied to the reference's gradient record of the
+    # fixture, then every parameter of the HIP step is held to the per-parameter bound against it (assert_per_parameter_grads:
+    # floor / 3x the reference path's own bf16 error on that parameter)
+    ref = O.closed_form_init_(O.FusionWithEmotionDecoder(d_model=768, num_emotions=6, n_heads=8, dropout=0.0)).train()
+    loss_r, logits_r, ga_r, gt_r, gr = _train_step(ref, h_a, h_t, m_a, m_t, g["y"])
+    close(loss_r.reshape(1), g["loss"], 1e-5, "oracle loss vs golden")
+    for n in gr:
+        close(gr[n].norm().reshape(1), g["g.norm." + n], 1e-4, "oracle grad norm vs golden " + n)
+    _, _, ga_y, gt_y, gy = _train_step(ref, h_a, h_t, m_a, m_t, g["y"], autocast_cpu=True)
+    m.train()
+    loss_m, logits_m, ga_m, gt_m, gm = _train_step(m, cu(h_a), cu(h_t), cu(m_a), cu(m_t), cu(g["y"]))
+    assert abs(float(loss_m) - float(g["loss"])) <= 2e-3 * max(1.0, abs(float(g["loss"])))
+    gm = {n: v.float().cpu() for n, v in gm.items()}
+    rows = assert_per_parameter_grads(gm, gy, gr, what="cfg2 shape vs golden-tied oracle")
+    print("cfg-2 shape: worst five (mine, yardstick, parameter):", [(f"{a:.3f}", f"{b:.3f}", n) for a, b, n in rows[:5]])
+    ea, ya = _rel(ga_m, ga_r), _rel(ga_y, ga_r)
+    et, yt = _rel(gt_m, gt_r), _rel(gt_y, gt_r)
+    assert ea <= max(GRAD_FLOOR, GRAD_FACTOR * ya) and et <= max(GRAD_FLOOR, GRAD_FACTOR * yt), (ea, ya, et, yt)
+
+
 def test_components_vs_golden(H):
     g = load_golden("block_eval_ragged")
     blk = O.closed_form_init_(H.CrossModalBlock(128, 8, 0.1)).cuda().eval()

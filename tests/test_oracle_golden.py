@@ -98,6 +98,34 @@ def test_fusion_train_grads(name, d, ne):
             close((p.detach() - before[n]).norm().reshape(1), g["delta.norm." + n], 1e-3)
 
 
+def test_cfg2_shape_seeded_eval_and_train_step():
+    """the oracle at the HEADLINE shape (d=768, T_a=400, T_t=128, N_e=6, B=2, ragged) against the reference's outputs, loss and
+    gradient record"""
+    from conftest import cfg2_seeded_inputs
+    g = load_golden("cfg2_seeded")
+    h_a, h_t, m_a, m_t = cfg2_seeded_inputs(g)
+    m = _fusion(768, 6, p=0.0).eval()
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+    close(logits, g["logits"]); close(beta, g["beta"]); close(z, g["z"])
+    m.train()
+    h_a = h_a.clone().requires_grad_(True)
+    h_t = h_t.clone().requires_grad_(True)
+    lt, bt, zt = m(h_a, h_t, m_a, m_t)
+    loss = O.train_step_loss(lt, bt, g["y"])
+    loss.backward()
+    close(loss.reshape(1), g["loss"])
+    close(h_a.grad.norm().reshape(1), g["g_h_a_norm"], 1e-4); close(h_t.grad.norm().reshape(1), g["g_h_t_norm"], 1e-4)
+    close(h_a.grad.reshape(-1)[torch.linspace(0, h_a.numel() - 1, 256).long()], g["g_h_a_samp"], 1e-4)
+    for n, p in m.named_parameters():
+        close(p.grad.norm().reshape(1), g["g.norm." + n], 1e-4)
+        if "g.full." + n in g:
+            close(p.grad, g["g.full." + n], 1e-4)
+        else:
+            flat = p.grad.reshape(-1)
+            close(flat[torch.linspace(0, flat.numel() - 1, 64).long()], g["g.samp." + n], 1e-4)
+
+
 def test_hd96_eval_and_maps():
     g = load_golden("hd96_eval_ragged")
     m = _fusion(768, 6, p=0.0).eval()
