@@ -25,11 +25,11 @@ def golden():
     return load_golden
 
 
-def cfg2_seeded_inputs(g):
-    """inputs of tests/golden/cfg2_seeded.npz (the headline shape, B=2): regenerated from the generator seed make_golden.py used,
-    verified against the stored probes -- the fixture holds no inputs"""
-    B, Ta, Tt, d = 2, 400, 128, 768
-    gen = torch.Generator().manual_seed(21)
+def cfg2_seeded_inputs(g, seed=21, Ta=400, Tt=128, d=768):
+    """inputs of tests/golden/cfg2_seeded.npz (the headline shape, B=2) and of its cfg4 / cfg5 siblings: regenerated from the
+    generator seed make_golden.py used, verified against the stored probes -- the fixtures hold no inputs"""
+    B = 2
+    gen = torch.Generator().manual_seed(seed)
     h_a = torch.randn(B, Ta, d, generator=gen)
     h_t = torch.randn(B, Tt, d, generator=gen)
     probe = torch.cat([h_a[0, 0, :8], h_t[1, -1, -8:], h_a.sum().reshape(1), h_t.sum().reshape(1)])

@@ -178,6 +178,24 @@ def cfg2_seeded_case():
         g_h_t_samp=h_t.grad.reshape(-1)[torch.linspace(0, h_t.numel() - 1, 256).long()], **grad_record(m))
 
 
+def other_config_cases():
+    """BASELINE.json configs[3] (MOSEI shape d=768, T_a=1000, T_t=50, N_e=6) and configs[4]'s dimensions (d=1024, 4 fusion + 2
+    decoder layers, N_e=7, T_a=400, T_t=128), B=2, ragged masks: outputs and the trainer loss only, inputs regenerated from the
+    seed like cfg2_seeded."""
+    for name, seed, cfg, (Ta, Tt) in (("cfg4_seeded", 31, dict(d_model=768, num_emotions=6, n_heads=8), (1000, 50)),
+                                      ("cfg5_seeded", 41, dict(d_model=1024, num_emotions=7, n_heads=8, num_layers_fusion=4,
+                                                               num_layers_decoder=2), (400, 128))):
+        B, d = 2, cfg["d_model"]
+        m = closed_form_init_(FusionWithEmotionDecoder(dropout=0.0, **cfg)).eval()
+        h_a, h_t, m_a, m_t = inputs(seed, B, Ta, Tt, d, True)
+        probe = torch.cat([h_a[0, 0, :8], h_t[1, -1, -8:], h_a.sum().reshape(1), h_t.sum().reshape(1)])
+        with torch.no_grad():
+            logits, beta, z = m(h_a, h_t, m_a, m_t)
+        y = (torch.rand(B, cfg["num_emotions"], generator=torch.Generator().manual_seed(seed + 1)) < 0.3).float()
+        loss = train_step_loss(logits, beta, y)
+        npz(name, probe=probe, mask_a=m_a, mask_t=m_t, y=y, logits=logits, beta=beta, z=z, loss=loss.reshape(1))
+
+
 def component_cases():
     d, H, B = 128, 8, 4
     # CrossModalBlock alone (a1-a5)
@@ -303,8 +321,12 @@ if __name__ == "__main__":
     if only == "cfg2_seeded":
         cfg2_seeded_case()
         sys.exit(0)
+    if only == "other_configs":
+        other_config_cases()
+        sys.exit(0)
     fusion_cases()
     cfg2_seeded_case()
+    other_config_cases()
     component_cases()
     mosei_case()
     legacy_cases()

@@ -262,6 +262,20 @@ def test_cfg2_shape_vs_reference_golden(H):
     assert ea <= max(GRAD_FLOOR, GRAD_FACTOR * ya) and et <= max(GRAD_FLOOR, GRAD_FACTOR * yt), (ea, ya, et, yt)
 
 
+@pytest.mark.parametrize("name,seed,Ta,Tt,kw", [("cfg4_seeded", 31, 1000, 50, dict(d_model=768, num_emotions=6, n_heads=8)),
+                                                ("cfg5_seeded", 41, 400, 128, dict(d_model=1024, num_emotions=7, n_heads=8,
+                                                                                   num_layers_fusion=4, num_layers_decoder=2))])
+def test_other_baseline_configs_vs_reference_golden(H, name, seed, Ta, Tt, kw):
+    """BASELINE configs[3] (MOSEI shape) and configs[4]'s dimensions (bf16 GEMMs) against outputs generated from the reference"""
+    from conftest import cfg2_seeded_inputs
+    g = load_golden(name)
+    h_a, h_t, m_a, m_t = cfg2_seeded_inputs(g, seed, Ta, Tt, kw["d_model"])
+    m = O.closed_form_init_(H.FusionWithEmotionDecoder(dropout=0.0, **kw)).cuda().eval()
+    with torch.no_grad():
+        logits, beta, z = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    close(logits, g["logits"], what="logits"); close(beta, g["beta"], what="beta"); close(z, g["z"], what="z")
+
+
 def test_components_vs_golden(H):
     g = load_golden("block_eval_ragged")
     blk = O.closed_form_init_(H.CrossModalBlock(128, 8, 0.1)).cuda().eval()

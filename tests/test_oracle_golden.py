@@ -126,6 +126,21 @@ def test_cfg2_shape_seeded_eval_and_train_step():
             close(flat[torch.linspace(0, flat.numel() - 1, 64).long()], g["g.samp." + n], 1e-4)
 
 
+@pytest.mark.parametrize("name,seed,Ta,Tt,kw", [("cfg4_seeded", 31, 1000, 50, dict(d_model=768, num_emotions=6, n_heads=8)),
+                                                ("cfg5_seeded", 41, 400, 128, dict(d_model=1024, num_emotions=7, n_heads=8,
+                                                                                   num_layers_fusion=4, num_layers_decoder=2))])
+def test_other_baseline_configs_seeded(name, seed, Ta, Tt, kw):
+    """the oracle at BASELINE configs[3] (MOSEI shape) and at configs[4]'s dimensions against the reference's outputs"""
+    from conftest import cfg2_seeded_inputs
+    g = load_golden(name)
+    h_a, h_t, m_a, m_t = cfg2_seeded_inputs(g, seed, Ta, Tt, kw["d_model"])
+    m = O.closed_form_init_(O.FusionWithEmotionDecoder(dropout=0.0, **kw)).eval()
+    with torch.no_grad():
+        logits, beta, z = m(h_a, h_t, m_a, m_t)
+    close(logits, g["logits"]); close(beta, g["beta"]); close(z, g["z"])
+    close(O.train_step_loss(logits, beta, g["y"]).reshape(1), g["loss"])
+
+
 def test_hd96_eval_and_maps():
     g = load_golden("hd96_eval_ragged")
     m = _fusion(768, 6, p=0.0).eval()
