@@ -1096,8 +1096,14 @@ class GradJoin:
 GRAD_JOIN = _os.environ.get("HRIEMO_GRAD_JOIN", "1") != "0"
 
 
-def grad_join(n=2):
-    return GradJoin(n) if (GRAD_JOIN and torch.is_grad_enabled()) else None
+JOIN_SCOPE = 0          # > 0 inside a forward whose outputs ALL depend on both encoder branches (FusionWithEmotionDecoder)
+
+
+def grad_join(n=2, always=False):
+    """a GradJoin where every consumer is certain to run its backward: the encoder's joins only inside the fusion model's forward
+    (a stand-alone CrossModalBlock may be trained on one of its two outputs, and the unused branch's consumers never run), the
+    decoder's (its layers are a chain) always"""
+    return GradJoin(n) if (GRAD_JOIN and torch.is_grad_enabled() and (always or JOIN_SCOPE > 0)) else None
 
 
 class KVProjFn(torch.autograd.Function):

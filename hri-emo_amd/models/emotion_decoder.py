@@ -106,7 +106,7 @@ class EmotionDecoder(nn.Module):
             side.wait_stream(main)
             _ops.share(memory16, side)
             with torch.cuda.stream(side):
-                jm = _ops.grad_join(len(self.layers)) if len(self.layers) > 1 else None      # the layers' memory gradients meet in one dX GEMM
+                jm = _ops.grad_join(len(self.layers), always=True) if len(self.layers) > 1 else None      # the layers' memory gradients meet in one dX GEMM
                 kvs = [_ops.KVProjFn.apply(memory16, l.cross_attn.in_proj_weight, l.cross_attn.in_proj_bias, l._sh, jm) for l in self.layers]
                 ready = torch.cuda.Event()
                 ready.record(side)

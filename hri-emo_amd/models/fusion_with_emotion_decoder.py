@@ -88,7 +88,11 @@ class FusionWithEmotionDecoder(nn.Module):
         t, t32 = _ops.as_pair(h_t)
         _ops.begin_step()
         ready = self._prefetch_shadows(a.device)
-        a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+        _ops.JOIN_SCOPE += 1          # logits, beta and z all depend on both branches: the encoder's gradient joins are safe
+        try:
+            a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+        finally:
+            _ops.JOIN_SCOPE -= 1
         if ready is not None:
             torch.cuda.current_stream(a.device).wait_event(ready)
         h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)

@@ -720,6 +720,11 @@ def test_shared_activation_gradients_joined_in_the_gemm_epilogue(H, monkeypatch)
     worst = max(float((grads[0][n] - grads[1][n]).norm() / grads[1][n].norm().clamp_min(1e-20)) for n in grads[0])
     assert worst <= 1e-2, worst              # the joined path rounds (g1 + g2) once, autograd rounds g1, g2 and their sum
     monkeypatch.setattr(_ops, "GRAD_JOIN", True)
+    # a stand-alone block trained on ONE of its outputs: the text branch's consumers never run, so no join may be active there
+    blk = H.CrossModalBlock(256, 8, 0.0).cuda().train()
+    oa, ot = blk(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    oa.float().pow(2).mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in blk.parameters() if p.grad is not None)
     j = _ops.GradJoin(2)
     x = torch.randn(2, 8, 128, device="cuda", requires_grad=True)
     w = torch.nn.Parameter(torch.randn(384, 128, device="cuda") * 0.05)
