@@ -1,0 +1,40 @@
+"""Whole-step soak: the captured cfg-2 step (dropout 0.1) replayed N times from the SAME dropout seed word must give bit-identical
+gradients and loss every time -- every kernel sums in a fixed order, so any differing bit is a fault (a race, a lost lane, an
+instruction hazard like the one of DESIGN.md 3.2), not noise.  Prints the number of differing replays and elements."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hri_emo_amd as H
+from hri_emo_amd import _ops
+from hri_emo_amd.dp import DataParallelStep
+from hri_emo_amd.train import fusion_step_loss
+import bench
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+dev = torch.device("cuda", 0)
+torch.manual_seed(1234)
+model = H.FusionWithEmotionDecoder(**bench.CFG).to(dev).train()
+dp = DataParallelStep(model, fusion_step_loss, overlap=False)
+dp.set_global_batch(64)
+batch = bench.synth(64, 0, dev)
+dp.step(*batch)
+dp.capture(*batch)
+sw = _ops.seed_word(dev)
+ref = None
+bad_replays = bad_elems = 0
+for i in range(n):
+    sw.fill_(12345)
+    loss = dp.step(*batch)
+    torch.cuda.synchronize()
+    g = dp.buckets.flat.view(torch.int32)
+    if ref is None:
+        ref, ref_loss = g.clone(), loss.clone()
+        print(f"reference replay: loss {float(loss):.6f}, |grad| {float(dp.buckets.flat.norm()):.6f}, {g.numel()} gradient words", flush=True)
+        continue
+    d = int((g != ref).sum())
+    if d or not torch.equal(loss, ref_loss):
+        bad_replays += 1
+        bad_elems += d
+        if bad_replays <= 5:
+            idx = (g != ref).nonzero().flatten()[:4].tolist()
+            print(f"  replay {i}: {d} differing gradient words (first at {idx}), loss {float(loss):.8f} vs {float(ref_loss):.8f}", flush=True)
+print(f"STEP SOAK {'CLEAN' if bad_replays == 0 else 'DIRTY'}: {bad_replays} of {n - 1} replays differ ({bad_elems} words) -- "
+      f"{(n - 1) * ref.numel():.3g} gradient words compared")
