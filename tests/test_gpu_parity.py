@@ -734,6 +734,38 @@ def test_shared_activation_gradients_joined_in_the_gemm_epilogue(H, monkeypatch)
         kv.float().sum().backward()          # the join's other consumer never arrives
 
 
+def test_captured_step_replays_bit_identically_from_one_seed(H):
+    """Every kernel sums in a fixed order: the captured training step (dropout 0.1, both streams, single-pass attention backward,
+    deferred reduces and weight gradients) replayed from the SAME dropout seed word must reproduce loss and all gradient words
+    bit for bit.  A race, a lost lane or an instruction hazard shows up here as differing words (scripts_dev/soak_step.py is
+    the long version at the cfg-2 size)."""
+    from hri_emo_amd import _ops
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(9)
+    m = H.FusionWithEmotionDecoder(d_model=768, num_emotions=6, n_heads=8, dropout=0.1).cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(16, 400, 128, 768, 77)
+    y = (torch.rand(16, 6, generator=torch.Generator().manual_seed(3)) < 0.3).float()
+    batch = (cu(h_a).bfloat16(), cu(h_t).bfloat16(), cu(m_a), cu(m_t), cu(y))
+    dp = DataParallelStep(m, fusion_step_loss, overlap=False)
+    dp.set_global_batch(16)
+    dp.step(*batch)
+    dp.capture(*batch)
+    sw = _ops.seed_word(batch[0].device)
+    ref = None
+    for i in range(12):
+        sw.fill_(4242)
+        loss = dp.step(*batch)
+        torch.cuda.synchronize()
+        g = dp.buckets.flat.view(torch.int32)
+        if ref is None:
+            ref, ref_loss = g.clone(), loss.clone()
+            assert torch.isfinite(dp.buckets.flat).all() and float(dp.buckets.flat.norm()) > 0
+            continue
+        assert torch.equal(loss, ref_loss), (i, float(loss), float(ref_loss))
+        assert torch.equal(g, ref), (i, int((g != ref).sum()))
+
+
 def test_trimmed_batch_gives_the_same_outputs(H):
     """dropping the columns that are PAD for every sample (data.trim_padding) must not change what
     the model returns -- PAD keys are masked, PAD query rows feed nothing."""
