@@ -38,6 +38,8 @@ _SIGS = {
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
     "hriemo_add_ln_fwd_mx8": ("pppppppppiiffQpIlpplp", "i"),
+    "hriemo_add_ln_fwd_rows": ("pppppppppiiffQpIlpplpp", "i"),
+    "hriemo_add_ln_bwd_rows": ("ppppppppppppiiifQpIlppp", "i"),
     "hriemo_add_ln_bwd_workspace_bytes": ("ii", "l"),
     "hriemo_add_ln_bwd": ("ppppppppppppiiifQpIlpp", "i"),
     "hriemo_colsum_workspace_bytes": ("ii", "l"),

@@ -598,7 +598,7 @@ def attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off):
     return out
 
 
-def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False, want_mx=False):
+def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False, want_mx=False, rows=None):
     """y = LN(x + drop(g)); x32 = fp32 twin of the residual stream (used instead of x when given);
     want32 -> also return the fp32 twin of y; want_mx -> also the MX-fp8 copy (bytes, scales) of y as a 5th result."""
     M, d = g.shape
@@ -606,6 +606,16 @@ def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False
     y32 = torch.empty((M, d), dtype=torch.float32, device=g.device) if want32 else None
     mean = torch.empty(M, dtype=torch.float32, device=g.device)
     rstd = torch.empty(M, dtype=torch.float32, device=g.device)
+    if rows is not None:          # packed rows: the dropout hash is keyed by the row of the padded layout
+        yq = ys = None
+        ld = 0
+        if want_mx:
+            ld = _lib.lib().hriemo_mx8_scale_ld(M)
+            yq = torch.empty((M, d), dtype=torch.uint8, device=g.device)
+            ys = torch.empty((d // 32, ld), dtype=torch.uint8, device=g.device)
+        _lib.call("hriemo_add_ln_fwd_rows", _p(g), _p(x), _p(x32), _p(gamma), _p(beta), _p(y), _p(y32), _p(mean), _p(rstd), M, d,
+                  _EPS, float(p), seed, _p(seed_word(g.device)), site, row_off, _p(yq), _p(ys), ld, _p(rows), _stream())
+        return (y, y32, mean, rstd, (yq, ys)) if want_mx else (y, y32, mean, rstd)
     if want_mx:
         ld = _lib.lib().hriemo_mx8_scale_ld(M)
         yq = torch.empty((M, d), dtype=torch.uint8, device=g.device)
@@ -618,8 +628,10 @@ def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False
     return y, y32, mean, rstd
 
 
-def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True, outs=None, accumulate=False, x32=None):
-    """outs = (dgamma, dbeta, dbias) destination tensors (fp32 [d]); fresh ones when None."""
+def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True, outs=None, accumulate=False, x32=None, rows=None):
+    """outs = (dgamma, dbeta, dbias) destination tensors (fp32 [d]); fresh ones when None.  rows: the row index that keys the
+    dropout hash (packed sequences), see add_ln_fwd."""
+    row_index = rows          # (`rows` below counts partial rows)
     M, d = g.shape
     dev = g.device
     dx = torch.empty((M, d), dtype=BF16, device=dev) if want_dx else None
@@ -631,14 +643,14 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
     if accumulate and DEFER_REDUCE and _in_backward():
         rows = L_.hriemo_add_ln_bwd_partial_rows(M, d)
         part = torch.empty(rows * 3 * d, dtype=torch.float32, device=dev)
-        _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), None,
-                  None, None, 0, M, d, float(p), seed, _p(seed_word(dev)), site, row_off, _p(part), _stream())
+        _lib.call("hriemo_add_ln_bwd_rows", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), None,
+                  None, None, 0, M, d, float(p), seed, _p(seed_word(dev)), site, row_off, _p(part), _p(row_index), _stream())
         _deferred.add(part, 3 * d, rows, d, 3 if outs[2] is not None else 2, [o for o in outs if o is not None], True)
     else:
         ws = workspace(L_.hriemo_add_ln_bwd_workspace_bytes(M, d), dev, slot=1)
-        _lib.call("hriemo_add_ln_bwd", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
+        _lib.call("hriemo_add_ln_bwd_rows", _p(dy), _p(g), _p(x), _p(x32), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg), _p(outs[0]),
                   _p(outs[1]), _p(outs[2]), int(accumulate), M, d, float(p), seed, _p(seed_word(dev)), site, row_off,
-                  _p(ws), _stream())
+                  _p(ws), _p(row_index), _stream())
     if dg is None:
         dg = dx           # no dropout: both branches get the same gradient
     return dx, dg, outs[0], outs[1], outs[2]
@@ -896,11 +908,11 @@ class SelfAttnLN(torch.autograd.Function):
         hd = _heads(d, H)
         M = B * L
         # packed sequences (x is [1, N_valid, d], the kpm slot carries the Seq): the attention sees AB samples of up to AL rows
-        AB, AL, cu = B, L, None
+        AB, AL, cu, RL, rows = B, L, None, L, None          # RL / rows: row stride and row index that key the LayerNorm dropout
         if isinstance(kpm, Seq):
             if need_w:
                 raise ValueError("attention maps are exported by the padded path only")
-            AB, AL, cu, kpm = kpm.B, kpm.Lmax, (kpm.cu, kpm.cu), None
+            AB, AL, cu, RL, rows, kpm = kpm.B, kpm.Lmax, (kpm.cu, kpm.cu), kpm.L, kpm.idx, None
         x2 = _contig_bf16(x).view(M, d)
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
@@ -910,12 +922,12 @@ class SelfAttnLN(torch.autograd.Function):
         o, lse, mbits = attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, AL, hd) else \
             attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * AL, x32=x32v, want32=TWIN,
-                                             want_mx=want_mx_copy(M, d))
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
+                                             want_mx=want_mx_copy(M, d), rows=rows)
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
-        ctx.packed = (AB, AL, cu)
+        ctx.packed = (AB, AL, cu, RL, rows)
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*( [probs] if probs is not None else []))
         return tag_mx(y.view(B, L, d), mx[0] if mx else None), (y32.view(B, L, d) if y32 is not None else None), probs
@@ -924,16 +936,16 @@ class SelfAttnLN(torch.autograd.Function):
     def backward(ctx, dy, dy32, _dprobs):
         x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, L, d, H, hd, p, seed, site, b_off = ctx.cfg
-        AB, AL, cu = ctx.packed
+        AB, AL, cu, RL, rows = ctx.packed
         M = B * L
         dev = x2.device
         dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(M, d)
         p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
-        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * AL,
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * RL,
                                                    outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
-                                                   accumulate=acc, x32=x32v)
+                                                   accumulate=acc, x32=x32v, rows=rows)
         dw_out = sink.buf(p_w_out)
         linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
@@ -972,12 +984,12 @@ class CrossAttnLN(torch.autograd.Function):
         Lk = xkv.shape[1]
         hd = _heads(d, H)
         # packed sequences: the kpm slot carries (Seq of the query side, Seq of the key side)
-        AB, ALq, ALk, cu = B, Lq, Lk, None
+        AB, ALq, ALk, cu, RL, rows = B, Lq, Lk, None, Lq, None
         if isinstance(kpm, tuple):
             if need_w:
                 raise ValueError("attention maps are exported by the padded path only")
             sq, sk = kpm
-            AB, ALq, ALk, cu, kpm = sq.B, sq.Lmax, sk.Lmax, (sq.cu, sk.cu), None
+            AB, ALq, ALk, cu, RL, rows, kpm = sq.B, sq.Lmax, sk.Lmax, (sq.cu, sk.cu), sq.L, sq.idx, None
         xq2 = _contig_bf16(xq).view(B * Lq, d)
         xq32 = _c32(xq32)
         x32v = xq32.view(B * Lq, d) if xq32 is not None else None
@@ -992,12 +1004,12 @@ class CrossAttnLN(torch.autograd.Function):
         o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd) else \
             attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * ALq, x32=x32v, want32=TWIN,
-                                             want_mx=want_mx_copy(B * Lq, d))
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
+                                             want_mx=want_mx_copy(B * Lq, d), rows=rows)
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
-        ctx.packed = (AB, ALq, ALk, cu)
+        ctx.packed = (AB, ALq, ALk, cu, RL, rows)
         ctx.kv_pre = kv_pre is not None
         ctx.join_q = join_q
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
@@ -1008,15 +1020,15 @@ class CrossAttnLN(torch.autograd.Function):
     def backward(ctx, dy, dy32, _dprobs):
         xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
-        AB, ALq, ALk, cu = ctx.packed
+        AB, ALq, ALk, cu, RL, rows = ctx.packed
         dev = xq2.device
         dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(B * Lq, d)
         p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
-        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * ALq,
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * RL,
                                                    outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
-                                                   accumulate=acc, x32=x32v)
+                                                   accumulate=acc, x32=x32v, rows=rows)
         dw_out = sink.buf(p_w_out)
         linear_dw(dg, o, dw_out, acc)
         do = linear_dx(dg, w_out16)
@@ -1150,7 +1162,8 @@ class FFNLN(torch.autograd.Function):
     """y = LN(x + drop(W2 . drop_mid(relu(W1 x + b1)) + b2))"""
 
     @staticmethod
-    def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off):
+    def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off, seq=None):
+        """seq: the Seq of packed rows (x is [1, N_valid, d]): keys the LayerNorm dropout by the rows of the padded layout"""
         if precision() == "fp32":
             _fp32().guard(ctx, "feed-forward sub-layer")
             return _fp32().ffn_ln(x, x32, w1, b1, w2, b2, gamma, beta, sh)
@@ -1170,7 +1183,11 @@ class FFNLN(torch.autograd.Function):
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
         g = proj_fwd(hd_, sh, w2, w2_16, b2)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * L, x32=x32v, want32=TWIN,
+        RL, rows = (seq.L, seq.idx) if seq is not None else (L, None)
+        if seq is not None and p_mid > 0:
+            raise ValueError("FFNLN: packed rows with a mid-FFN dropout are not built (the encoder's FFNs have none)")
+        ctx.rowkey = (RL, rows)
+        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, rows=rows, x32=x32v, want32=TWIN,
                                              want_mx=want_mx_copy(M, d))
         ctx.save_for_backward(x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
         ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)
@@ -1187,9 +1204,10 @@ class FFNLN(torch.autograd.Function):
         p_w1, p_b1, p_w2, p_b2, p_gamma, p_beta = ctx.params
         sink = GradSink(ctx.params)
         acc = sink.fused
-        ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * L,
+        RL, rows = ctx.rowkey
+        ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dy2, g, x2, gamma, mean, rstd, p, seed, site + 1, b_off * RL,
                                                 outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b2)),
-                                                accumulate=acc, x32=x32v)
+                                                accumulate=acc, x32=x32v, rows=rows)
         dw2 = sink.buf(p_w2)
         linear_dw(dg, hd_, dw2, acc)
         db1 = sink.buf(p_b1)
@@ -1208,7 +1226,7 @@ class FFNLN(torch.autograd.Function):
         dx = linear_dx(da, w1_16, epi=3, aux=ds)
         sink.done()
         r = sink.ret
-        return (dx.view(B, L, d), None, r(dw1), r(db1), r(dw2), r(db2), r(dgamma), r(dbeta)) + (None,) * 6
+        return (dx.view(B, L, d), None, r(dw1), r(db1), r(dw2), r(db2), r(dgamma), r(dbeta)) + (None,) * 7
 
 
 class BetaGateFn(torch.autograd.Function):

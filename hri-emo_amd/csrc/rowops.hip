@@ -11,10 +11,12 @@
 
 #define EPS_DEFAULT 1e-5f
 
-struct RowDrop { uint64_t seed; const unsigned long long* seed_dev; uint32_t site, thr16; float inv_keep; };
+// rowmap (optional): the row index that keys the dropout hash, for rows that were gathered from a larger layout (packed varlen
+// sequences: packed row -> row of the padded [B*L] layout), so that a packed launch drops exactly the elements the padded one drops
+struct RowDrop { uint64_t seed; const unsigned long long* seed_dev; uint32_t site, thr16; float inv_keep; const long long* rowmap; };
 static RowDrop row_drop(float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site) {
   DropCfg d = make_drop(p, seed, site);
-  RowDrop r; r.seed = seed; r.seed_dev = seed_dev; r.site = site; r.thr16 = d.thr16; r.inv_keep = d.inv_keep;
+  RowDrop r; r.seed = seed; r.seed_dev = seed_dev; r.site = site; r.thr16 = d.thr16; r.inv_keep = d.inv_keep; r.rowmap = nullptr;
   return r;
 }
 __device__ __forceinline__ uint32_t row_key(const RowDrop& dr) {
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const bf16_t* __restric
         bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
         load_resid(X, X32, row * d + ch * 8, xf);
         bool kp8[8];
-        row_keep8(key32, dr.thr16, (uint32_t)(row_offset + row), ch, kp8);
+        row_keep8(key32, dr.thr16, (uint32_t)(row_offset + (dr.rowmap != nullptr ? (long)dr.rowmap[row] : (long)row)), ch, kp8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float gv = kp8[j] ? gf[j] * dr.inv_keep : 0.f;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
         bf8_to_f32(*(const bf16x8*)(G + row * d + ch * 8), gf);
         load_resid(X, X32, row * d + ch * 8, xf);
         bf8_to_f32(*(const bf16x8*)(dY + row * d + ch * 8), dyf);
-        row_keep8(key32, dr.thr16, (uint32_t)(row_offset + row), ch, kp[c]);
+        row_keep8(key32, dr.thr16, (uint32_t)(row_offset + (dr.rowmap != nullptr ? (long)dr.rowmap[row] : (long)row)), ch, kp[c]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float gv = kp[c][j] ? gf[j] * dr.inv_keep : 0.f;
@@ -381,7 +383,7 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict_
     float f[8];
     bf8_to_f32(*(const bf16x8*)(X + v * 8), f);
     bool kp8[8];
-    row_keep8(key32, dr.thr16, (uint32_t)(row_offset + row), ch, kp8);
+    row_keep8(key32, dr.thr16, (uint32_t)(row_offset + (dr.rowmap != nullptr ? (long)dr.rowmap[row] : (long)row)), ch, kp8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = kp8[j] ? f[j] * dr.inv_keep : 0.f;
     *(bf16x8*)(Y + v * 8) = f32_to_bf8(f);
@@ -757,10 +759,12 @@ static int lnb_cap(int d) {
 
 static int add_ln_fwd_impl(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
                            float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
-                           const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy, hipStream_t st) {
+                           const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
+                           const long long* row_index, hipStream_t st) {
   if (check_rows(M, d)) return 1;
   HRIEMO_CHECK(Yq == nullptr || (d % 32 == 0 && SY != nullptr && ldsy >= M), "add_ln_fwd: the MX-fp8 copy needs d %% 32 == 0 and a scale buffer");
   RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
+  dr.rowmap = row_index;
   hriemo_prof_begin(HP_ROWOPS, st);
 #define CALL(N) hipLaunchKernelGGL((add_ln_fwd_kernel<N>), dim3(row_grid(M, 4096)), dim3(256), 0, st, (const bf16_t*)G, (const bf16_t*)X, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset, (uint8_t*)Yq, (uint8_t*)SY, ldsy)
   DISPATCH_NCH(d, CALL)
@@ -772,7 +776,7 @@ static int add_ln_fwd_impl(const void* G, const void* X, const float* X32, const
 extern "C" int hriemo_add_ln_fwd(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
                                  float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
                                  const unsigned long long* seed_dev, unsigned site, long row_offset, hipStream_t st) {
-  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, nullptr, nullptr, 0, st);
+  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, nullptr, nullptr, 0, nullptr, st);
 }
 // same, plus the MX-fp8 copy of Y (bytes [M][d], scales [d/32][ldsy]) for the next projection / FFN GEMM (hriemo_gemm_mx8)
 extern "C" int hriemo_add_ln_fwd_mx8(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
@@ -780,18 +784,28 @@ extern "C" int hriemo_add_ln_fwd_mx8(const void* G, const void* X, const float* 
                                      const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
                                      hipStream_t st) {
   HRIEMO_CHECK(Yq != nullptr, "add_ln_fwd_mx8: Yq required");
-  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, Yq, SY, ldsy, st);
+  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, Yq, SY, ldsy, nullptr, st);
+}
+
+// same as hriemo_add_ln_fwd (Yq / SY may be NULL) with the dropout hash keyed by row_index[row] instead of row
+extern "C" int hriemo_add_ln_fwd_rows(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                                      float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                                      const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
+                                      const long long* row_index, hipStream_t st) {
+  return add_ln_fwd_impl(G, X, X32, gamma, beta, Y, Y32, mean, rstd, M, d, eps, p_drop, seed, seed_dev, site, row_offset, Yq, SY, ldsy,
+                         row_index, st);
 }
 
 extern "C" long hriemo_add_ln_bwd_workspace_bytes(int M, int d) { return ((long)row_grid(M, lnb_cap(d)) * 3 * d + 64L * 3 * d) * 4; }
 
-extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
-                                 const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
-                                 int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
-                                 unsigned site, long row_offset, float* workspace, hipStream_t st) {
+static int add_ln_bwd_impl(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
+                           const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                           int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                           unsigned site, long row_offset, float* workspace, const long long* row_index, hipStream_t st) {
   if (check_rows(M, d)) return 1;
   HRIEMO_CHECK(workspace != nullptr, "add_ln_bwd: workspace required");
   RowDrop dr = row_drop(p_drop, seed, seed_dev, site);
+  dr.rowmap = row_index;
   const int nb = row_grid(M, lnb_cap(d));
   hriemo_prof_begin(HP_ROWOPS, st);
 #define CALL(N) hipLaunchKernelGGL((add_ln_bwd_kernel<N>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
@@ -805,6 +819,21 @@ extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, c
   launch_colreduce(workspace, (long)3 * d, nb, ro, d, dbias != nullptr ? 3 : 2, accumulate, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
+}
+
+extern "C" int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
+                                 const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                                 int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                                 unsigned site, long row_offset, float* workspace, hipStream_t st) {
+  return add_ln_bwd_impl(dY, G, X, X32, gamma, mean, rstd, dX, dG, dgamma, dbeta, dbias, accumulate, M, d, p_drop, seed, seed_dev, site,
+                         row_offset, workspace, nullptr, st);
+}
+extern "C" int hriemo_add_ln_bwd_rows(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
+                                      const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                                      int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                                      unsigned site, long row_offset, float* workspace, const long long* row_index, hipStream_t st) {
+  return add_ln_bwd_impl(dY, G, X, X32, gamma, mean, rstd, dX, dG, dgamma, dbeta, dbias, accumulate, M, d, p_drop, seed, seed_dev, site,
+                         row_offset, workspace, row_index, st);
 }
 
 extern "C" int hriemo_add_ln_bwd_partial_rows(int M, int d) { (void)d; return row_grid(M, lnb_cap(d)); }

@@ -52,9 +52,9 @@ class CrossModalBlock(nn.Module):
         gradient the OTHER cross-attention returns for the same tensor as its query side in a GradJoin"""
         return _ops.KVProjFn.apply(xkv, mha.in_proj_weight, mha.in_proj_bias, self._sh, join)
 
-    def _ffn(self, x, x32, ffn, ln, p, seed, site):
+    def _ffn(self, x, x32, ffn, ln, p, seed, site, seq=None):
         return _ops.FFNLN.apply(x, x32, ffn[0].weight, ffn[0].bias, ffn[2].weight, ffn[2].bias, ln.weight, ln.bias,
-                                self._sh, p, 0.0, seed, site, self.batch_offset)
+                                self._sh, p, 0.0, seed, site, self.batch_offset, seq)
 
     def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, plan=None):
         """(bf16, fp32-twin) pairs in and out; returns (a, a32, t, t32, maps|None).
@@ -93,10 +93,10 @@ class CrossModalBlock(nn.Module):
             kv_a2t = self._kv(t_s, self.attn_a2t, jt) if use_kv else None
             x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
                                         kv_a2t, ja)                                                                # :98-105
-            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])                              # :106
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)                              # :106
             x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
                                         kv_t2a, jt)                                                                # :111-118
-            t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])                              # :119
+            t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None)                              # :119
         else:
             # The audio and text branches only meet at the two cross-attentions (each reads the OTHER branch's
             # self-attention output), so the text branch runs on a second stream: its small grids (B*T_t rows)
@@ -124,10 +124,10 @@ class CrossModalBlock(nn.Module):
             with torch.cuda.stream(side):
                 x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
                                             kv_t2a, jt)
-                t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5])
+                t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None)
             x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
                                         kv_a2t, ja)
-            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3])
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)
             main.wait_stream(side)
             for x_ in (t_cm, t_cm32, w_t, w_t2a):
                 _ops.share(x_, main)

@@ -144,6 +144,17 @@ int hriemo_add_ln_fwd_mx8(const void* G, const void* X, const float* X32, const 
                           float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
                           const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
                           hriemo_stream_t stream);
+/* hriemo_add_ln_fwd / _bwd for rows gathered from a larger layout (packed varlen sequences): the dropout hash is keyed by
+ * row_index[row] (int64 [M], e.g. the row of the padded [B*L] layout) instead of row, so the packed launch drops exactly the
+ * elements the padded one drops.  Yq / SY (MX-fp8 copy) may be NULL. */
+int hriemo_add_ln_fwd_rows(const void* G, const void* X, const float* X32, const float* gamma, const float* beta, void* Y,
+                           float* Y32, float* mean, float* rstd, int M, int d, float eps, float p_drop, unsigned long long seed,
+                           const unsigned long long* seed_dev, unsigned site, long row_offset, void* Yq, void* SY, long ldsy,
+                           const long long* row_index, hriemo_stream_t stream);
+int hriemo_add_ln_bwd_rows(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
+                           const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
+                           int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                           unsigned site, long row_offset, float* workspace, const long long* row_index, hriemo_stream_t stream);
 long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
 int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
                       const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,

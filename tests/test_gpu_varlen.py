@@ -172,10 +172,10 @@ def test_train_step_gradients_varlen_vs_padded(H):
     print(f"packed vs padded gradients: worst relative L2 difference {worst:.2e}; valid fraction audio {float(la.sum()) / (B * Ta):.2f} text {float(lt.sum()) / (B * Tt):.2f}")
 
 
-def test_train_step_with_dropout_runs_packed(H):
-    """dropout on: the attention masks are keyed by position within the sequence (identical packed / padded, checked at kernel
-    level above), the LayerNorm / FFN masks by row, which packing renumbers -- so the two steps are different draws of the same
-    model: finite, and close in loss"""
+def test_train_step_with_dropout_packed_equals_padded(H):
+    """dropout on: the attention masks are keyed by position within the sequence and the LayerNorm masks by the row of the PADDED
+    layout (hriemo_add_ln_*_rows), so a packed step draws exactly the masks of the padded step from the same seed: loss and every
+    parameter gradient agree to fp32 summation-order tolerance, as with dropout off"""
     from hri_emo_amd.train import fusion_step_loss
     torch.manual_seed(3)
     m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=5, n_heads=8, dropout=0.1).cuda().train()
@@ -183,18 +183,26 @@ def test_train_step_with_dropout_runs_packed(H):
     B, Ta, Tt, d = 8, 120, 48, 256
     h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda(), torch.randn(B, Tt, d, generator=g).cuda()
     la = torch.randint(30, Ta + 1, (B,), generator=g); lt = torch.randint(10, Tt + 1, (B,), generator=g)
+    la[0], lt[0] = Ta, Tt
     m_a, m_t = (torch.arange(Ta)[None] >= la[:, None]).cuda(), (torch.arange(Tt)[None] >= lt[:, None]).cuda()
     y = (torch.rand(B, 5, generator=g) < 0.3).float().cuda()
-    losses = []
+    runs = []
     for packed in (False, True):
         H.set_varlen(packed)
         m.zero_grad(set_to_none=True)
+        torch.manual_seed(77)                      # the step's dropout seed comes from torch's generator
         logits, beta, z = m(h_a, h_t, m_a, m_t)
         loss = fusion_step_loss(logits, beta, y)
         loss.backward()
-        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
-        losses.append(float(loss))
-    assert abs(losses[0] - losses[1]) < 0.1 * max(1.0, abs(losses[0])), losses
+        runs.append((float(loss), {n: p.grad.detach().float().clone() for n, p in m.named_parameters()}))
+    (l0, g0), (l1, g1) = runs
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (l0, l1)
+    worst = max(float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-20)) for n in g0)
+    assert worst <= 1e-4, worst
+    torch.manual_seed(78)
+    H.set_varlen(True)
+    l2 = float(fusion_step_loss(*m(h_a, h_t, m_a, m_t)[:2], y))
+    assert abs(l2 - l1) > 1e-6                     # and another seed is another draw (the dropout is really on)
 
 
 def test_captured_step_refuses_other_masks_in_packed_mode(H):
