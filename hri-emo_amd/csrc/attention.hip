@@ -804,8 +804,9 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
   constexpr int LDS_ONE = 2 * IMG + KT_BYTES + 2 * DST_BYTES;
   // PAIR: one workgroup of 2*NW waves = two independent (batch, head) problems, each with its own NW waves and its own LDS half;
   // they only share the barriers (same trip counts).  The fused kernel at 128 keys needs half the CU's LDS and a full register
-  // budget per problem: as TWO workgroups per CU it returned wrong dS elements on hardware (one workgroup per CU was exact, with
-  // or without spills, exact LDS fit or not -- scripts_dev/dbg_attn.py), as one paired workgroup it keeps two waves per SIMD.
+  // budget per problem; two problems per workgroup keep two waves per SIMD with ONE workgroup per CU (exactly two 80 KB
+  // workgroups would also fit, but a paired one does not depend on the dispatcher co-scheduling them).  (The wrong dS elements
+  // once seen at two waves per SIMD were the packed subtract pinned further down, not the pairing.)
   __shared__ __attribute__((aligned(16))) char lds_all[LDS_ONE * (PAIR ? 2 : 1)];
   const int sub = PAIR ? (int)(threadIdx.x / (NW * 64)) : 0;
   char* const lds = lds_all + sub * LDS_ONE;
