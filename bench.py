@@ -175,12 +175,22 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return tt.item()
         t_eager = probe()
-        dp.buckets.suspended = True
-        dp.capture(*batch)
-        dp.use_graph(True)
-        t_graph = probe()
+        ok, t_graph = 1, float("inf")
+        try:                                       # the replay mode is optional: if its capture fails on this node, stay eager
+            dp.buckets.suspended = True
+            dp.capture(*batch)
+            dp.use_graph(True)
+        except Exception as e:                     # noqa: BLE001
+            ok = 0
+            log(f"rank {rank}: capturing the step failed ({type(e).__name__}: {e}); eager mode only")
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # every rank takes the same branch
+        if int(flag.item()) == 1:
+            t_graph = probe()
         use_graph = t_graph < t_eager
         dp.use_graph(use_graph)
+        if not use_graph:
+            dp.buckets.suspended = False
         log(f"N={world}: eager + overlapped exchange {t_eager * 1e3:.3f} ms/step, replay + exchange after {t_graph * 1e3:.3f} ms/step -> "
             f"{'replay' if use_graph else 'eager'}")
     for _ in range(a.warmup):
