@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnAr
 template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED, bool PAIR = false, bool PACKED = false>
 // two waves per SIMD are only requested where the kernel fits 256 registers WITHOUT spilling: co-resident blocks of the spilling
 // builds gave wrong dS elements on hardware (scripts_dev/dbg_attn.py; a single block per CU of the same code was exact)
-__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <= 96 && NW == 4 && KW == 1) ? 3 : ((PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED)))) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a0) {
+__global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <= 96 && NW == 4 && KW == 1) ? 3 : ((PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED) || FUSED))) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a0) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
   static_assert(QT == 32, "query tile");
@@ -1355,10 +1355,10 @@ static bool bwd_wide(int L, int BH, int head_dim) {
 static bool bwd_fused(int Lk, int head_dim, int B, int H) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
-  // (the paired kernel puts heads 2j, 2j+1 of ONE sample into a workgroup -- same trip counts also with packed sequences of
-  // different lengths; an odd number of heads cannot be paired: two-kernel path)
-  (void)B;
-  return on && Lk > 16 && Lk <= 128 && head_dim >= 32 && (H % 2 == 0 || (head_dim == 128 && Lk > 64));
+  // (one workgroup per (batch, head); HRIEMO_ATTN_PAIR=1 puts heads 2j, 2j+1 of one sample into a 512-thread workgroup instead --
+  // measured slower, its barriers couple the two problems)
+  (void)B; (void)H;
+  return on && Lk > 16 && Lk <= 128 && head_dim >= 32;
 }
 
 extern "C" int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim) { return bwd_fused(Lk, head_dim, B, H) ? 1 : 0; }
@@ -1416,8 +1416,12 @@ static int attn_bwd_impl(const void* Q, long ldq, const void* K, long ldk, const
 #define CALLF(HD, KW_, BITS_)                                                                                                    \
   {                                                                                                                              \
     constexpr int lds_one__ = 4 * 32 * AttnGeom<HD>::STRIDE + (4 * KW_ * 16) * AttnGeom<HD>::STRIDE + 2 * (4 * KW_ * 16) * 96;     \
+    static const bool pair__ = [] { const char* e = getenv("HRIEMO_ATTN_PAIR"); return e && e[0] == '1'; }();                     \
     if constexpr (2 * lds_one__ <= 160 * 1024) {                                                                                 \
-      if ((B * H) % 2 == 0) {                                                                                                    \
+      if (!pair__ || (B * H) % 2 != 0) {       /* two independent workgroups per CU (own barriers): a2t backward 66 us vs 80 paired */ \
+        if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false, true>), dim3(B * H), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);      \
+      } else if ((B * H) % 2 == 0) {                                                                                             \
         if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true, true>), dim3(B * H / 2), dim3(512), 0, st, a); \
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true>), dim3(B * H / 2), dim3(512), 0, st, a);   \
       }                                                                                                                          \
