@@ -131,3 +131,29 @@ def test_collate_matches_reference_fixture_and_trim_and_bucketing():
     waste = lambda bs: sum(max(lengths[i] for i in b) * len(b) - sum(lengths[i] for i in b) for b in bs)
     plain = [list(range(s, min(s + 32, 1003))) for s in range(0, 1003, 32)]
     assert waste(batches) < 0.25 * waste(plain)
+
+
+def test_packed_sequence_plan_and_row_round_trip():
+    """host logic of the packed (varlen) path, no GPU needed: prefix masks give cu_seqlens and the packed-row -> padded-row index;
+    anything else (a hole inside the prefix, an all-PAD row) gives no plan; pack / unpack are inverse on the valid rows"""
+    import torch
+    from hri_emo_amd import _ops
+    B, L, d = 4, 7, 3
+    lens = torch.tensor([7, 1, 4, 5])
+    mask = torch.arange(L)[None, :] >= lens[:, None]
+    plan = _ops.seq_plan(mask, B, L)
+    assert plan is not None and plan.N == int(lens.sum()) and plan.Lmax == 7 and plan.L == L and plan.B == B
+    assert plan.cu.tolist() == [0, 7, 8, 12, 17]
+    assert plan.idx.tolist() == [b * L + l for b in range(B) for l in range(int(lens[b]))]
+    x = torch.arange(B * L * d, dtype=torch.float32).view(B, L, d)
+    packed = _ops.pack_rows(x, plan)
+    assert packed.shape == (1, plan.N, d)
+    back = _ops.unpack_rows(packed, plan)
+    valid = ~mask
+    assert torch.equal(back[valid], x[valid]) and float(back[mask].abs().sum()) == 0.0
+    hole = mask.clone(); hole[0, 2] = True
+    assert _ops.seq_plan(hole, B, L) is None
+    allpad = mask.clone(); allpad[1, :] = True
+    assert _ops.seq_plan(allpad, B, L) is None
+    assert _ops.seq_plan(None, B, L) is None
+
