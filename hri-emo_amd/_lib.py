@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhriemo.so")
+# HRIEMO_LIB: developer override (scripts_dev/forensics builds variant libraries); a path that does not exist still raises
+LIB_PATH = os.environ.get("HRIEMO_LIB") or os.path.join(_HERE, "libhriemo.so")
 
 _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float,
       "Q": ctypes.c_ulonglong, "I": ctypes.c_uint}
@@ -65,6 +66,7 @@ _SIGS = {
     "hriemo_rowsum_f32": ("ppilp", "i"),
     "hriemo_gate_input_pooled": ("pppiip", "i"),
     "hriemo_fusion_loss": ("ppppiiiffpppp", "i"),
+    "hriemo_fusion_loss_ce": ("pppiiiffpppp", "i"),
     "hriemo_scalar_gate_dx": ("pipippppiiip", "i"),
     "hriemo_fuse_bwd_dw": ("ppppiiip", "i"),
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),

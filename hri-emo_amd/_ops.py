@@ -1465,6 +1465,35 @@ class FusionLossFn(torch.autograd.Function):
         return gl, gb, None, None, None, None, None
 
 
+class FusionLossCEFn(torch.autograd.Function):
+    """Single-label trainer loss (train_fusion_seq_level_decoder.py:312-314,325-326,413-414): CrossEntropyLoss(logits, labels) +
+    reg(beta), value and gradients from ONE kernel (hriemo_fusion_loss_ce)."""
+
+    @staticmethod
+    def forward(ctx, logits, beta, labels, reg_mode, reg_coef, scale):
+        _require_gpu(logits)
+        B, C = logits.shape
+        x = logits.contiguous().float()
+        lb = labels.contiguous().to(torch.int64)
+        bt = beta.contiguous().float().view(B) if beta is not None else None
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        db = torch.empty(B, dtype=torch.float32, device=x.device) if bt is not None else None
+        _lib.call("hriemo_fusion_loss_ce", _p(x), _p(lb), _p(bt), B, C, int(reg_mode) if bt is not None else 0, float(reg_coef),
+                  float(scale), _p(loss), _p(dx), _p(db), _stream())
+        ctx.save_for_backward(dx, db)
+        ctx.shapes = (logits.shape, beta.shape if beta is not None else None, logits.dtype, beta.dtype if beta is not None else None)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, db = ctx.saved_tensors
+        ls, bs, ld, bd = ctx.shapes
+        gl = (dx * g).to(ld).view(ls)
+        gb = (db * g).to(bd).view(bs) if db is not None else None
+        return gl, gb, None, None, None, None
+
+
 class LinearFn(torch.autograd.Function):
     """y[..., N] (fp32) = x[..., K] . W[N,K]^T + b for any K (MOSEI projections: K = 74 / 300, padded to a
     multiple of 8 internally) -- models/mosei_fusion_with_emotion_decoder.py:41-42,63-65."""

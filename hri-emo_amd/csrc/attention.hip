@@ -785,8 +785,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_hash_kernel(const AttnAr
 // PACKED: cu_seqlens launch (localize()); a separate instantiation because this kernel runs at the 256-register limit and the
 // per-sample pointers of the packed view cost the padded launch 13 us of 82 (a2t backward at cfg 2) when they share one body
 template <int HD, int NW, int KW, int QT, bool BITS, bool FUSED, bool PAIR = false, bool PACKED = false>
-// two waves per SIMD are only requested where the kernel fits 256 registers WITHOUT spilling: co-resident blocks of the spilling
-// builds gave wrong dS elements on hardware (scripts_dev/dbg_attn.py; a single block per CU of the same code was exact)
+// two waves per SIMD (256 registers) wherever the kernel fits them without spilling inside its loops (`make check-isa` prints the
+// spill counts per kernel and fails on scratch traffic inside a loop of a default-path kernel)
 __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <= 96 && NW == 4 && KW == 1) ? 3 : ((PAIR || (HD <= 96 && NW == 4 && (KW == 1 || (BITS && !FUSED) || FUSED))) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a0) {
   using G = AttnGeom<HD>;
   constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NT = NW * 64;
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
   // they only share the barriers (same trip counts).  The fused kernel at 128 keys needs half the CU's LDS and a full register
   // budget per problem; two problems per workgroup keep two waves per SIMD with ONE workgroup per CU (exactly two 80 KB
   // workgroups would also fit, but a paired one does not depend on the dispatcher co-scheduling them).  (The wrong dS elements
-  // once seen at two waves per SIMD were the packed subtract pinned further down, not the pairing.)
+  // once seen at two waves per SIMD were a packed subtract -- see the (dP - delta') line further down -- not the pairing.)
   __shared__ __attribute__((aligned(16))) char lds_all[LDS_ONE * (PAIR ? 2 : 1)];
   const int sub = PAIR ? (int)(threadIdx.x / (NW * 64)) : 0;
   char* const lds = lds_all + sub * LDS_ONE;
@@ -901,9 +901,7 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
     tile_fetch<HD, QT, NT>(qr, Qb, a.ldq, qt * QT, a.Lq, tid);
     tile_fetch<HD, QT, NT>(dor, dOb, a.lddo, qt * QT, a.Lq, tid);
   };
-  int side_q = 0;                     // first query row of the tile whose sideband is in flight
   auto fetch_side = [&](int qt) {     // sideband of tile qt: global -> registers (threads tid < QT; fused: delta by all threads)
-    side_q = qt * QT;
     if (tid < QT) {
       const int q = qt * QT + tid;
       lse_r = q < a.Lq ? l2ik - a.lse[lbase + q] * LOG2E : -INFINITY;   // -inf -> p = 0 for rows past Lq
@@ -931,8 +929,7 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
       }
     }
     if (FUSED && (tid & 7) == 0) {
-      *(LDS_PTR(float))(base + (tid >> 3) * STRIDE + SB + 4) = del_part;
-      if (a.delta != nullptr && side_q + (tid >> 3) < a.Lq) a.delta[lbase + side_q + (tid >> 3)] = del_part;     // (1 - p) * rowsum(dO * O)
+      *(LDS_PTR(float))(base + (tid >> 3) * STRIDE + SB + 4) = del_part;        // (1 - p) * rowsum(dO * O); never leaves the block
     }
   };
   auto commit = [&](int buf) {        // Q / dO registers -> image `buf`
@@ -1014,14 +1011,12 @@ __global__ __launch_bounds__(NW * 64 * (PAIR ? 2 : 1), (!FUSED && !PAIR && HD <=
             pd = keep ? pk : 0.f;
             dpd = keep ? dpd : 0.f;
           }
-          // The subtraction is pinned to a scalar v_sub_f32: left to the compiler, the two key sub-tiles' (dP - delta') pairs
-          // of the BITS + FUSED variants become  v_pk_add_f32 d, a, b op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]  (both halves minus
-          // the high dword of the (lse', delta') pair), and with two waves per SIMD that build sporadically (~1e-5 of the
-          // elements, always the high half in lanes 48..63) produced dS = pk * dP, the subtraction lost -- measured with
-          // scripts_dev/dbg_attn.py; the instruction alone does not misbehave (scripts_dev/pkadd_probe.hip), the cause inside
-          // this instruction mix is not understood.  The scalar form is exact on the same tests.
-          float dif;
-          asm("v_sub_f32 %0, %1, %2" : "=v"(dif) : "v"(dpd), "v"(del4[r]));
+          // Plain C on purpose.  This file is built with -fno-slp-vectorize: hipcc's SLP vectoriser turned the two key sub-tiles'
+          // subtractions into  v_pk_add_f32 d, a, ld op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]  (ld = the (lse', delta') pair as
+          // loaded), and on MI355X the LOW result of that form -- the half whose src1 operand is taken from the HIGH dword --
+          // sporadically comes back as a.lo - 0 in lanes 48..63 (scripts_dev/forensics).  `make check-isa` fails
+          // the build if the form shows up in any code object again.
+          const float dif = dpd - del4[r];
           const float dsv = pk * dif;
           if (FUSED) dsum[kw] += dsv;
           pf[kw][qs >> 1][(qs & 1) * 4 + r] = (bf16_t)pd;
@@ -1349,9 +1344,9 @@ static bool bwd_wide(int L, int BH, int head_dim) {
 // Single-pass backward: one block holds all keys of a (batch, head) (16 < L_k <= 128) and produces dQ, dK and dV together
 // (5 GEMMs per tile instead of 7, Q/K/V/dO read once): a2t backward 82 us instead of 114 at cfg 2.
 // ON by default (HRIEMO_ATTN_FUSED_BWD=0 selects the two-kernel path).  Its first build returned a few wrong dS elements per
-// launch with the bit-word mask at two waves per SIMD; traced (scripts_dev/dbg_attn.py) to the compiler's packed form of the
-// (dP - delta') subtraction, pinned to v_sub_f32 in the kernel since; 4.4e9 elements bit-identical between the bit-word and the
-// hash variant afterwards (scripts_dev/soak_attn.py, profiles/r02_attn_soak.log).
+// launch with the bit-word mask at two waves per SIMD; traced to the compiler's packed form of the (dP - delta') subtraction
+// (v_pk_add_f32 with the low result reading the high dword of src1: round 3's scripts_dev/forensics reproduce it in 20 of 20
+// runs and isolate the operand select); the file is compiled without SLP vectorisation since.
 static bool bwd_fused(int Lk, int head_dim, int B, int H) {
   static int on = -1;
   if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }

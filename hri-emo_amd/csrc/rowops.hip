@@ -1021,48 +1021,6 @@ __global__ __launch_bounds__(256) void gate_input_pooled_kernel(const float* __r
   }
 }
 
-// ------------------------------------------------------------------ trainer losses, value + gradient in one launch
-// loss = mean_{b,e} BCEWithLogits(x, y; pos_weight) + reg(beta), written with its gradients d loss / d logits, d loss / d beta:
-//   BCE (torch.nn.BCEWithLogitsLoss, scripts/fusion/train_mosei_fusion_seq_level_decoder.py:569):
-//        l = (1 - y) x + (1 + (pw - 1) y) softplus(-x)
-//   reg mode 1 (train_fusion_seq_level_decoder.py:318-326):  - coef * mean_b beta (1 - beta)
-//   reg mode 2 (train_mosei_fusion_seq_level_decoder.py:340-347, 385-386):  + coef * mean_b H(clamp(beta, eps, 1 - eps)), H = binary entropy
-// One block; [B, N_e] is a few hundred values.
-__global__ __launch_bounds__(256) void fusion_loss_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ pw,
-                                                          const float* __restrict__ beta, int B, int Ne, int mode, float coef, float scale,
-                                                          float* __restrict__ loss, float* __restrict__ dx, float* __restrict__ dbeta) {
-  __shared__ float red[8];
-  const int n = B * Ne;
-  float acc = 0.f;
-  const float inv_n = 1.f / (float)n, inv_b = 1.f / (float)B;
-  for (int t = threadIdx.x; t < n; t += 256) {
-    const float xv = x[t], yv = y[t];
-    const float lw = pw != nullptr ? 1.f + (pw[t % Ne] - 1.f) * yv : 1.f;
-    const float sp = log1pf(__expf(-fabsf(xv))) + fmaxf(-xv, 0.f);            // softplus(-x)
-    acc += ((1.f - yv) * xv + lw * sp) * inv_n;
-    const float sig = 1.f / (1.f + __expf(-xv));
-    dx[t] = ((1.f - yv) - lw * (1.f - sig)) * inv_n * scale;
-  }
-  for (int b = threadIdx.x; b < B; b += 256) {
-    float g = 0.f;
-    if (beta != nullptr && mode == 1) {
-      const float bv = beta[b];
-      acc += -coef * bv * (1.f - bv) * inv_b;
-      g = -coef * (1.f - 2.f * bv) * inv_b;
-    } else if (beta != nullptr && mode == 2) {
-      const float eps = 1e-8f, raw = beta[b];
-      const float bv = fminf(fmaxf(raw, eps), 1.f - eps);
-      acc += -coef * (bv * __logf(bv) + (1.f - bv) * __logf(1.f - bv)) * inv_b;
-      g = (raw > eps && raw < 1.f - eps) ? coef * (__logf(1.f - bv) - __logf(bv)) * inv_b : 0.f;
-    }
-    if (dbeta != nullptr) dbeta[b] = g * scale;
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
-}
-
 // ------------------------------------------------------------------ optimizer (trainer step, off the timed path)
 // partial[blockIdx.x] = sum of squares of this block's grid-stride share (fixed grid: deterministic)
 __global__ __launch_bounds__(256) void sumsq_f32_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
@@ -1152,16 +1110,6 @@ extern "C" int hriemo_gate_input_pooled(const float* a_pool, const float* t_pool
   HRIEMO_CHECK(B > 0 && d > 0, "gate_input_pooled: empty");
   hipLaunchKernelGGL(gate_input_pooled_kernel, dim3(B), dim3(256), 0, st, a_pool, t_pool, (bf16_t*)gate_in, d);
   HRIEMO_LAUNCH_CHECK("gate_input_pooled_kernel");
-  return 0;
-}
-
-extern "C" int hriemo_fusion_loss(const float* logits, const float* targets, const float* pos_weight, const float* beta, int B, int Ne,
-                                  int reg_mode, float reg_coef, float scale, float* loss, float* dlogits, float* dbeta, hipStream_t st) {
-  HRIEMO_CHECK(B > 0 && Ne > 0 && loss != nullptr && dlogits != nullptr, "fusion_loss: bad arguments");
-  HRIEMO_CHECK(reg_mode >= 0 && reg_mode <= 2, "fusion_loss: reg_mode %d (0 none, 1 -c*mean(b(1-b)), 2 +c*entropy)", reg_mode);
-  hipLaunchKernelGGL(fusion_loss_kernel, dim3(1), dim3(256), 0, st, logits, targets, pos_weight, beta, B, Ne, reg_mode, reg_coef, scale, loss,
-                     dlogits, dbeta);
-  HRIEMO_LAUNCH_CHECK("fusion_loss_kernel");
   return 0;
 }
 

@@ -210,6 +210,12 @@ int hriemo_gate_input_pooled(const float* a_pool, const float* t_pool, void* gat
  * (1/grad_accum).  Writes loss[1], dlogits[B,N_e], dbeta[B] (dbeta may be NULL). */
 int hriemo_fusion_loss(const float* logits, const float* targets, const float* pos_weight, const float* beta, int B, int Ne,
                        int reg_mode, float reg_coef, float scale, float* loss, float* dlogits, float* dbeta, hriemo_stream_t stream);
+/* Single-label variant, torch.nn.CrossEntropyLoss() as scripts/fusion/train_fusion_seq_level_decoder.py:413-414 builds it (mean
+ * over the batch, no class weights, no label smoothing), plus the same beta regulariser (:325-326): labels[B] are int64 class
+ * indices in [0, C) (an index outside poisons the loss with NaN instead of reading out of bounds).  Writes loss[1],
+ * dlogits[B,C] = (softmax - onehot)/B * scale, dbeta[B] (may be NULL). */
+int hriemo_fusion_loss_ce(const float* logits, const long long* labels, const float* beta, int B, int C, int reg_mode,
+                          float reg_coef, float scale, float* loss, float* dlogits, float* dbeta, hriemo_stream_t stream);
 int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, const float* dpool, const float* cnt,
                           const unsigned char* mask, void* dX, int B, int L, int d, hriemo_stream_t stream);
 /* Trainer step off the timed path, scripts/fusion/train_fusion_seq_level_decoder.py:332-334: clip_grad_norm_(5.0) +

@@ -302,3 +302,44 @@ def test_fusion_loss_kernel_value_and_gradients(lib, B, Ne, mode, coef, pw, scal
     assert (xd.grad.cpu() / 3.0 - x.grad).abs().max() <= 2e-6 * max(1.0, x.grad.abs().max().item())
     if mode:
         assert (bd.grad.cpu() / 3.0 - beta.grad).abs().max() <= 1e-5 * max(1e-3, beta.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,mode,coef,scale", [(64, 4, 1, 0.01, 1.0), (8, 6, 0, 0.0, 1.0), (300, 7, 2, 0.05, 0.5), (1, 2, 1, 0.01, 1.0), (5, 1, 1, 0.01, 1.0)])
+def test_fusion_loss_ce_kernel_value_and_gradients(lib, B, C, mode, coef, scale):
+    """hriemo_fusion_loss_ce (single-label branch of the IEMOCAP trainer, train_fusion_seq_level_decoder.py:312-314,325-326 with
+    criterion nn.CrossEntropyLoss() :413-414) against torch.nn.functional.cross_entropy + the beta regulariser, value and both
+    gradients, through the autograd Function; and through hri_emo_amd.train.fusion_step_loss_single_label."""
+    from hri_emo_amd import _ops
+    from hri_emo_amd.train import fusion_step_loss_single_label
+    g = torch.Generator().manual_seed(B * 10 + C)
+    x = (torch.randn(B, C, generator=g) * 4).requires_grad_(True)
+    lab = torch.randint(0, C, (B,), generator=g)
+    beta = torch.rand(B, 1, generator=g).requires_grad_(True)
+    ref = F.cross_entropy(x, lab)
+    if mode == 1:
+        ref = ref - coef * (beta * (1 - beta)).mean()
+    elif mode == 2:
+        b = torch.clamp(beta, 1e-8, 1 - 1e-8)
+        ref = ref + coef * (-(b * torch.log(b) + (1 - b) * torch.log(1 - b))).mean()
+    ref = ref * scale
+    ref.backward()
+    xd, bd = x.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+    loss = _ops.FusionLossCEFn.apply(xd, bd if mode else None, lab.cuda(), mode, coef, scale)
+    (loss * 3.0).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert (xd.grad.cpu() / 3.0 - x.grad).abs().max() <= 2e-6 * max(1.0, x.grad.abs().max().item())
+    if mode:
+        assert (bd.grad.cpu() / 3.0 - beta.grad).abs().max() <= 1e-5 * max(1e-3, beta.grad.abs().max().item())
+    if mode == 1 and coef == 0.01 and scale == 1.0:
+        l2 = fusion_step_loss_single_label(x.detach().cuda(), beta.detach().cuda(), lab.cuda())
+        assert abs(float(l2) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        cpu = fusion_step_loss_single_label(x.detach(), beta.detach(), lab)          # the CPU formula the gloo tests use
+        assert abs(float(cpu) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+
+
+def test_fusion_loss_ce_label_out_of_range_is_nan(lib):
+    """torch raises for a class index outside [0, C); a kernel cannot, so the loss is poisoned instead of reading out of bounds"""
+    from hri_emo_amd import _ops
+    x = torch.randn(4, 3).cuda()
+    loss = _ops.FusionLossCEFn.apply(x, None, torch.tensor([0, 2, 3, 1]).cuda(), 0, 0.0, 1.0)
+    assert torch.isnan(loss).item()
