@@ -93,6 +93,21 @@ def side_stream(device):
     return s
 
 
+CAPTURE_ORIGIN = None      # the stream dp.DataParallelStep.capture() captures on (None outside a capture)
+
+
+def fork(child, parent):
+    """`child` starts to depend on `parent`: a stream fork.  While a step is being captured, every fork has to start at the
+    capture's origin stream: a helper stream forked from an already forked stream (a fork nested inside a fork) makes
+    hipStreamEndCapture segfault on ROCm 7.2 (gpurun_out/seg.log of round 2) -- raw HIP events or torch streams
+    alike -- so that shape is refused here, as a Python exception, before anything reaches the runtime."""
+    if CAPTURING and CAPTURE_ORIGIN is not None and parent != CAPTURE_ORIGIN and child != CAPTURE_ORIGIN:
+        raise RuntimeError("hri_emo_amd: a stream was forked from a stream that is itself a fork of the capture stream; ROCm 7.2 "
+                           "crashes in hipStreamEndCapture on nested forks -- fork helper streams from the capturing stream only "
+                           "(join the side stream back first), or run this step eagerly")
+    child.wait_stream(parent)
+
+
 _main_streams = {}
 
 
@@ -725,8 +740,23 @@ _deferred = _DeferredReduce()
 GATE_TWO_STREAMS = _os.environ.get("HRIEMO_GATE_TWO_STREAMS", "1") != "0"     # the gate's text-side LayerNorm + pooling on the side stream
 DEFER_SMALL_DW = _os.environ.get("HRIEMO_DEFER_SMALL_DW", "1") != "0"
 SMALL_DW_ROWS = 1024
-FLUSH_AFTER_SITE = None            # dropout-site id of the sub-layer whose backward ends the text branch (set by CrossModalTransformer)
-grad_hooks_active = lambda: False  # noqa: E731  (dp.GradBuckets installs the real test)
+FLUSH_SITES = set()                # dropout-site ids of the sub-layers whose backward ends a model's text branch (one per CrossModalTransformer)
+_hook_predicates = []              # one per live dp.GradBuckets with gradient-ready hooks (register_hook_predicate)
+
+
+def register_hook_predicate(fn):
+    """dp.GradBuckets: `fn()` is True while its gradient-ready hooks drive an overlapped exchange"""
+    _hook_predicates.append(fn)
+    return fn
+
+
+def unregister_hook_predicate(fn):
+    if fn in _hook_predicates:
+        _hook_predicates.remove(fn)
+
+
+def grad_hooks_active():
+    return any(f() for f in _hook_predicates)
 
 
 class _DeferredWgrad:
@@ -960,7 +990,7 @@ class SelfAttnLN(torch.autograd.Function):
             colsum(dqkv, db_in, acc)
         dx = linear_dx(dqkv, w_in16, epi=3, aux=ds)
         sink.done()
-        if site == FLUSH_AFTER_SITE:
+        if site in FLUSH_SITES:
             _small_dw.flush()                 # the text branch's backward ends here: queued decoder / gate weight gradients go out now
         r = sink.ret
         return (dx.view(B, L, d), None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8
@@ -1260,7 +1290,7 @@ class BetaGateFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         side = side_stream(dev) if GATE_TWO_STREAMS else None
         if side is not None and side != main:
-            side.wait_stream(main)
+            fork(side, main)
             with torch.cuda.stream(side):
                 _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt),
                           B, Lt, L, d, _EPS, _stream())
@@ -1330,7 +1360,7 @@ class BetaGateFn(torch.autograd.Function):
         side = side_stream(dev) if GATE_TWO_STREAMS else None
         if side is not None and side != main:
             # text on the side stream (its own workspace there), audio on this one; joined before the gradients are handed back
-            side.wait_stream(main)
+            fork(side, main)
             with torch.cuda.stream(side):
                 ws_t = workspace(L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d), dev, slot=1)
                 _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),

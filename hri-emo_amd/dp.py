@@ -61,10 +61,25 @@ class GradBuckets:
         self._hooks = []
         if overlap and self.world > 1:
             from . import _ops
-            _ops.grad_hooks_active = lambda: bool(self._hooks) and not self.suspended      # an overlapped exchange wants gradients in production order
+            # an overlapped exchange wants gradients in production order; one predicate per GradBuckets (a second instance --
+            # an eval or EMA wrapper -- must not switch the first one's deferral of small weight-gradient GEMMs on or off)
+            self._predicate = _ops.register_hook_predicate(lambda: bool(self._hooks) and not self.suspended)
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 p._hriemo_grad_ready = self._on_grad_sink     # gradients the kernels accumulate in place (_ops.GradSink)
+
+    def close(self):
+        """remove the gradient-ready hooks and this instance's predicate (the parameters keep their flat-buffer views)"""
+        from . import _ops
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if getattr(self, "_predicate", None) is not None:
+            _ops.unregister_hook_predicate(self._predicate)
+            self._predicate = None
+        for p in self.params:
+            if getattr(p, "_hriemo_grad_ready", None) == self._on_grad_sink:
+                del p._hriemo_grad_ready
 
     # -- hooks ---------------------------------------------------------------------------------
     def _launch(self, bi):
@@ -154,8 +169,11 @@ class DataParallelStep:
     shadows are re-cast inside the graph so optimizer updates between replays are honoured.  The gradient
     all-reduce runs after the replay on the flat buffer."""
 
+    _capture_streams = {}         # device index -> the one stream every capture of this process records on
+
     def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True, comm_dtype=torch.float32):
         self.model, self.loss_fn = model, loss_fn
+        self._keep = []
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype)
@@ -201,7 +219,13 @@ class DataParallelStep:
         if self.buckets._hooks and not self.buckets.suspended:
             raise RuntimeError("capture() needs GradBuckets(overlap=False) or buckets.suspended = True: collectives are not captured")
         self._static = [None if t is None else t.clone() for t in (h_a, h_t, m_a, m_t, y)]
-        side = torch.cuda.Stream()
+        self.release_graph()              # a re-capture replaces the old graph: its pinned buffers go first
+        # ONE capture stream per device for every capture of the process: workspaces are keyed by stream, a fresh stream per
+        # capture would allocate (and, with a graph alive, retire instead of free) a fresh 64 MB+ set each time
+        dev = self._static[0].device
+        side = DataParallelStep._capture_streams.get(dev.index)
+        if side is None:
+            side = DataParallelStep._capture_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture wants
             for _ in range(2):
@@ -210,6 +234,7 @@ class DataParallelStep:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         _ops.CAPTURING = True
+        _ops.CAPTURE_ORIGIN = side        # every helper-stream fork of the step must start here (_ops.fork refuses nested forks)
         _ops.begin_step()
         try:
             # capture on the stream the warm-up ran on: its workspaces (keyed by stream) exist already, so nothing the
@@ -220,10 +245,27 @@ class DataParallelStep:
                 self._static_loss = self._fwd_bwd(*self._static)
         finally:
             _ops.CAPTURING = False
+            _ops.CAPTURE_ORIGIN = None
         _ops.GRAPHS_ALIVE += 1            # from now on outgrown workspaces are retired, not freed (_ops.workspace)
+        # buffers the captured kernels point into (column-sum partials, queued weight-gradient operands) live exactly as long as
+        # this graph: they move from the process-wide lists to the graph's owner
+        self._keep = _ops._deferred.keep + _ops._small_dw.keep
+        _ops._deferred.keep, _ops._small_dw.keep = [], []
         self._packed = _ops.varlen()      # the graph bakes the sequence lengths of THIS batch in (packed rows, cu_seqlens)
+        self._mask_seen = {}              # k -> (data_ptr, _version) of the caller's mask tensor last compared with the captured one
         self._graph = graph
         self._replay = True
+
+    def release_graph(self):
+        """drop the captured step (before a re-capture, or to free its buffers): the graph, the buffers its kernels point into"""
+        from . import _ops
+        if self._graph is not None:
+            torch.cuda.synchronize()
+            self._graph = None
+            self._keep = []
+            _ops.GRAPHS_ALIVE = max(0, _ops.GRAPHS_ALIVE - 1)
+            if _ops.GRAPHS_ALIVE == 0:
+                del _ops._ws_retired[:]   # no graph points into the outgrown workspaces any more
 
     def use_graph(self, on):
         """Switch between the captured replay (gradient exchange after it) and eager launches (exchange from the
@@ -236,10 +278,15 @@ class DataParallelStep:
             for k, (s, t) in enumerate(zip(self._static, (h_a, h_t, m_a, m_t, y))):
                 if s is not None and t is not None and s.data_ptr() != t.data_ptr():
                     if getattr(self, "_packed", False) and k in (2, 3):
+                        # the comparison is a host-device sync: once per distinct caller tensor (address + version), not per step
+                        seen = (t.data_ptr(), t._version)
+                        if self._mask_seen.get(k) == seen:
+                            continue
                         if not torch.equal(s, t.to(s.dtype)):
                             raise RuntimeError("DataParallelStep: this step was captured with packed (varlen) sequences; its graph can "
                                                "only be replayed with the padding masks it was captured with -- use_graph(False) or "
                                                "capture per length pattern")
+                        self._mask_seen[k] = seen
                         continue
                     s.copy_(t)
             self._graph.replay()

@@ -82,13 +82,16 @@ class CrossModalBlock(nn.Module):
         # other one.  With the K | V projections as their own nodes, created BEFORE both cross-attention cores, the engine runs
         # the cores' backward first (they deposit the query-side gradients) and the projections' backward last, where one
         # dX GEMM adds the deposit in its epilogue: no elementwise add launches on [B*L, d] (_ops.GradJoin).
+        # A join exists only where BOTH consumers are certain to get a backward node that must produce the shared activation's
+        # gradient, i.e. where that activation requires grad: with a frozen cross-attention and inputs that need no gradient the
+        # partner's node never runs and a deposit would be stranded (autograd then sums whatever gradients there are).
         ja = jt = None
         use_kv = not fp32
-        if use_kv:
-            ja, jt = _ops.grad_join(2), _ops.grad_join(2)
+        join_for = lambda x: _ops.grad_join(2) if (use_kv and x.requires_grad) else None          # noqa: E731
         if side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
             t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
+            ja, jt = join_for(a_s), join_for(t_s)
             kv_t2a = self._kv(a_s, self.attn_t2a, ja) if use_kv else None
             kv_a2t = self._kv(t_s, self.attn_a2t, jt) if use_kv else None
             x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
@@ -103,20 +106,21 @@ class CrossModalBlock(nn.Module):
             # fill the CUs the audio branch leaves idle.  Fork/join with stream waits; tensors that cross
             # streams are recorded on the consumer stream (allocator safety); autograd replays the same streams
             # in backward.
-            side.wait_stream(main)
+            _ops.fork(side, main)
             for x_ in (t, t32, kpm_t, kpm_a):
                 _ops.share(x_, side)
             with torch.cuda.stream(side):
                 t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
             main.wait_stream(side)
-            side.wait_stream(main)
+            _ops.fork(side, main)
             _ops.share(t_s, main)
             _ops.share(a_s, side)
             if fp32:
                 _ops.share(t_s32, main)
                 _ops.share(a_s32, side)
             kv_t2a = kv_a2t = None
+            ja, jt = join_for(a_s), join_for(t_s)
             if use_kv:
                 with torch.cuda.stream(side):
                     kv_t2a = self._kv(a_s, self.attn_t2a, ja)
@@ -153,7 +157,7 @@ class CrossModalTransformer(nn.Module):
     def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
         all_layers_attn = []
         plan = None
-        _ops.FLUSH_AFTER_SITE = self.layers[0]._site[1]      # layer-0 text self-attention: the last text-branch backward (_ops._DeferredWgrad)
+        _ops.FLUSH_SITES.add(self.layers[0]._site[1])        # layer-0 text self-attention: the last text-branch backward (_ops._DeferredWgrad)
         if _ops.varlen() and not need and mask_a is not None and mask_t is not None and _ops.precision() == "bf16":
             # the encoder on the valid rows only (prefix masks, as the collate builds them); anything else
             # takes the padded path

@@ -103,10 +103,10 @@ class EmotionDecoder(nn.Module):
         side = _ops.side_stream(memory16.device) if (_HOIST_KV and _ops.precision() == "bf16" and memory16.is_cuda) else None
         if side is not None:
             main = torch.cuda.current_stream(memory16.device)
-            side.wait_stream(main)
+            _ops.fork(side, main)
             _ops.share(memory16, side)
             with torch.cuda.stream(side):
-                jm = _ops.grad_join(len(self.layers), always=True) if len(self.layers) > 1 else None      # the layers' memory gradients meet in one dX GEMM
+                jm = _ops.grad_join(len(self.layers), always=True) if (len(self.layers) > 1 and memory16.requires_grad) else None      # the layers' memory gradients meet in one dX GEMM (only if the memory needs one: frozen layers would strand a deposit)
                 kvs = [_ops.KVProjFn.apply(memory16, l.cross_attn.in_proj_weight, l.cross_attn.in_proj_bias, l._sh, jm) for l in self.layers]
                 ready = torch.cuda.Event()
                 ready.record(side)

@@ -42,7 +42,7 @@ class FusionWithEmotionDecoder(nn.Module):
         if side is None:
             return None
         main = torch.cuda.current_stream(device)
-        side.wait_stream(main)                       # the masters may have just been updated on the caller's stream
+        _ops.fork(side, main)                       # the masters may have just been updated on the caller's stream
         with torch.cuda.stream(side):
             g = self.beta_gate
             g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))

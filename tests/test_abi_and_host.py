@@ -157,3 +157,38 @@ def test_packed_sequence_plan_and_row_round_trip():
     assert _ops.seq_plan(allpad, B, L) is None
     assert _ops.seq_plan(None, B, L) is None
 
+
+
+def test_nested_stream_fork_is_refused_during_capture():
+    """ROCm 7.2 segfaults in hipStreamEndCapture when a helper stream is forked from an already forked stream (round 2,
+    gpurun_out/seg.log); _ops.fork turns that shape into a Python exception.  Stream stand-ins: only identity and wait_stream
+    are used."""
+    from hri_emo_amd import _ops
+
+    class S:
+        def __init__(self): self.waited = []
+        def wait_stream(self, other): self.waited.append(other)
+
+    origin, side, helper = S(), S(), S()
+    _ops.fork(helper, side)                       # outside a capture anything goes
+    _ops.CAPTURING, _ops.CAPTURE_ORIGIN = True, origin
+    try:
+        _ops.fork(side, origin)                   # fork off the capture stream: fine
+        _ops.fork(origin, side)                   # join back: fine
+        with pytest.raises(RuntimeError, match="nested forks"):
+            _ops.fork(helper, side)
+        assert helper.waited == [side]            # only the eager call above reached the stream
+    finally:
+        _ops.CAPTURING, _ops.CAPTURE_ORIGIN = False, None
+
+
+def test_hook_predicates_are_per_instance():
+    """one GradBuckets must not overwrite another's 'gradient hooks active' predicate"""
+    from hri_emo_amd import _ops
+    a = _ops.register_hook_predicate(lambda: True)
+    b = _ops.register_hook_predicate(lambda: False)
+    assert _ops.grad_hooks_active()
+    _ops.unregister_hook_predicate(a)
+    assert not _ops.grad_hooks_active()
+    _ops.unregister_hook_predicate(b)
+    assert not _ops._hook_predicates

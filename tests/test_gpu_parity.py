@@ -734,6 +734,42 @@ def test_shared_activation_gradients_joined_in_the_gemm_epilogue(H, monkeypatch)
         kv.float().sum().backward()          # the join's other consumer never arrives
 
 
+def test_partial_fine_tuning_with_a_frozen_cross_attention(H, monkeypatch):
+    """a join is only created where both consumers of a shared activation get a backward node.  Layer 0 frozen except
+    its audio->text cross-attention, inputs without gradient: the t2a K|V projection node never exists, and the a2t core must
+    neither deposit into a join nor raise.  Same for a decoder whose memory needs no gradient and whose second layer's
+    cross-attention in-projection is frozen.  Gradients equal the HRIEMO_GRAD_JOIN=0 path."""
+    from hri_emo_amd import _ops
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(6)
+    m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=5, n_heads=8, dropout=0.0).cuda().train()
+    l0 = m.cross_modal.layers[0]
+    for n, p in l0.named_parameters():
+        p.requires_grad_(n.startswith("attn_a2t.") or n.startswith("norm_a1."))
+    h_a, h_t, m_a, m_t = _rand_batch(4, 90, 36, 256, 29)
+    y = (torch.rand(4, 5, generator=torch.Generator().manual_seed(3)) < 0.3).float().cuda()
+    grads = []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "GRAD_JOIN", on)
+        m.zero_grad(set_to_none=True)
+        logits, beta, z = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+        fusion_step_loss(logits, beta, y).backward()
+        grads.append({n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert set(grads[0]) == set(grads[1]) and "cross_modal.layers.0.attn_a2t.in_proj_weight" in grads[0]
+    assert not any(n.startswith("cross_modal.layers.0.attn_t2a") for n in grads[0])
+    worst = max(float((grads[0][n] - grads[1][n]).norm() / grads[1][n].norm().clamp_min(1e-20)) for n in grads[0])
+    assert worst <= 1e-2, worst
+    monkeypatch.setattr(_ops, "GRAD_JOIN", True)
+    dec = H.EmotionDecoder(d_model=256, num_emotions=5, n_heads=8, num_layers=2, dropout=0.0).cuda().train()
+    dec.layers[1].cross_attn.in_proj_weight.requires_grad_(False)
+    dec.layers[1].cross_attn.in_proj_bias.requires_grad_(False)
+    mem = torch.randn(4, 36, 256, device="cuda")                    # no gradient wanted for the memory
+    zq, lg = dec(mem, cu(m_t))
+    lg.float().pow(2).mean().backward()
+    assert dec.layers[0].cross_attn.in_proj_weight.grad is not None and dec.layers[1].cross_attn.in_proj_weight.grad is None
+    assert torch.isfinite(dec.layers[0].cross_attn.in_proj_weight.grad).all()
+
+
 def test_captured_step_replays_bit_identically_from_one_seed(H):
     """Every kernel sums in a fixed order: the captured training step (dropout 0.1, both streams, single-pass attention backward,
     deferred reduces and weight gradients) replayed from the SAME dropout seed word must reproduce loss and all gradient words
