@@ -50,7 +50,7 @@ _SIGS = {
     "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
     "hriemo_expand_rows": ("ppilp", "i"),
     "hriemo_rowdot_fwd": ("pppppiip", "i"),
-    "hriemo_rowdot_bwd": ("pppppppiip", "i"),
+    "hriemo_rowdot_bwd": ("pppppppiiip", "i"),
     "hriemo_pool_chunks": ("i", "i"),
     "hriemo_ln_pool_fwd": ("pppppppppiiiifp", "i"),
     "hriemo_gate_input": ("ppppiiiipppp" + "p", "i"),
@@ -72,7 +72,7 @@ _SIGS = {
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),
     "hriemo_gate_input_bwd": ("ppppppiip", "i"),
     "hriemo_ln_pool_bwd_workspace_bytes": ("iii", "l"),
-    "hriemo_ln_pool_bwd": ("pipipppppppppp" + "iiipp", "i"),
+    "hriemo_ln_pool_bwd": ("pipipppppppppp" + "iiiipp", "i"),
     "hriemo_prof_enable": ("i", "i"),
     "hriemo_prof_nclass": ("", "i"),
     "hriemo_prof_collect": ("ippp", "i"),

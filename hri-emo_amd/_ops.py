@@ -147,6 +147,7 @@ def new_site_base():
 
 
 _seed_words = {}
+_half_reports = {}         # id(parameter) -> SharedProjFn nodes that have written their half of its gradient in this step
 CAPTURING = False          # set by dp.DataParallelStep.capture(): weight shadows are re-cast inside the graph
 STEP_ID = 0                # bumped at the top of every model step (begin_step): "this shadow was already cast in this step"
 
@@ -154,6 +155,7 @@ STEP_ID = 0                # bumped at the top of every model step (begin_step):
 def begin_step():
     global STEP_ID
     STEP_ID += 1
+    _half_reports.clear()
 
 WEIGHTS_EPOCH = 0          # bumped by anything that rewrites parameter storage behind autograd's back (optim.FusedClipAdamW
                            # updates the flat buffer through raw pointers: p._version and p.data_ptr() do not move)
@@ -217,6 +219,44 @@ class Shadows:
         for p in params:
             self.get(p)
 
+    def get_cat(self, parts):
+        """bf16 shadow of the row-wise concatenation of master slices: parts = ((param, r0, r1), ...) -> [sum(r1 - r0), K].
+        One GEMM per shared input (SharedProjFn) reads it; refreshed when any of the masters changes, like get()."""
+        key = ("cat",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
+        ent = self._d.get(key)
+        ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
+        dev = parts[0][0].device
+        if (CAPTURING and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != dev:
+            rows = sum(r1 - r0 for _, r0, r1 in parts)
+            K = parts[0][0].shape[1]
+            s = ent[1] if ent is not None and ent[1].device == dev else torch.empty((rows, K), dtype=BF16, device=dev)
+            at = 0
+            for p, r0, r1 in parts:
+                _require_gpu(p)
+                _require_fp32_master(p)
+                src = p.detach()
+                if not src.is_contiguous():
+                    src = src.contiguous()
+                _lib.call("hriemo_cast_f32_to_bf16", _p(src[r0:r1]), _p(s[at:at + (r1 - r0)]), (r1 - r0) * K, _stream())
+                at += r1 - r0
+            ent = (ver, s, STEP_ID)
+            self._d[key] = ent
+        return ent[1]
+
+    def get_cat_vec(self, parts):
+        """fp32 concatenation of bias slices ((param, r0, r1), ...), cached like the weight shadows"""
+        key = ("catv",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
+        ent = self._d.get(key)
+        ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
+        if (CAPTURING and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver:
+            v = torch.cat([p.detach()[r0:r1] for p, r0, r1 in parts])
+            if ent is not None and ent[1].shape == v.shape and ent[1].device == v.device:
+                ent[1].copy_(v)           # same storage: a captured graph keeps pointing at it
+                v = ent[1]
+            ent = (ver, v, STEP_ID)
+            self._d[key] = ent
+        return ent[1]
+
 
 FUSED_WGRAD = True
 
@@ -254,15 +294,16 @@ class GradSink:
     def ret(self, t):
         return None if self.fused else t
 
-    def done(self, skip=()):
-        """skip: parameters another Function still adds to in this backward (it reports them)"""
+    def done(self, skip=(), after_flush=()):
+        """skip: parameters another Function still adds to in this backward (it reports them); after_flush: matrices whose
+        gradient is a column sum finished by the launch-boundary reduce, like the vectors"""
         if self.fused:
             for p in self.params:
                 if any(p is q for q in skip):
                     continue
                 hook = getattr(p, "_hriemo_grad_ready", None)
                 if hook is not None:
-                    if p.dim() < 2 and DEFER_REDUCE and _in_backward():
+                    if (p.dim() < 2 or any(p is q for q in after_flush)) and DEFER_REDUCE and _in_backward():
                         _deferred.add_hook(hook, p)       # bias / LayerNorm gradients are final only after the flush
                     elif p.dim() >= 2 and _small_dw.touches(p.grad):
                         _small_dw.add_hook(hook, p)       # its weight-gradient GEMM is still queued
@@ -1001,9 +1042,12 @@ class CrossAttnLN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w, kv_pre=None,
-                join_q=None):
+                join_q=None, q_pre=None, slots=None):
         """kv_pre: the K | V projection of xkv computed by KVProjFn ahead of time (the decoder hoists it onto the side stream); its
-        weight-gradient and dX then belong to that Function, this one returns dK | dV for it"""
+        weight-gradient and dX then belong to that Function, this one returns dK | dV for it.
+        q_pre: likewise the Q projection of xq (SharedProjFn: one GEMM per shared input); this Function then only returns dQ for it
+        and hands the residual-path gradient of xq to join_q.  slots = (SharedGrad of dQ, SharedGrad of dK|dV): where the attention
+        backward writes those gradients, so that they arrive at the projection's backward as column slices of ONE buffer."""
         if precision() == "fp32":
             _fp32().guard(ctx, "cross-attention sub-layer")
             return _fp32().cross_attn_ln(xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w)
@@ -1023,8 +1067,9 @@ class CrossAttnLN(torch.autograd.Function):
         xq2 = _contig_bf16(xq).view(B * Lq, d)
         xq32 = _c32(xq32)
         x32v = xq32.view(B * Lq, d) if xq32 is not None else None
-        w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
-        q = proj_fwd(Operand(xq2, mx_of(xq)), sh, w_in, w_in16, b_in, rows=(0, d))
+        w_out16 = sh.get(w_out)
+        w_in16 = sh.get(w_in) if (q_pre is None or kv_pre is None) else None
+        q = q_pre if q_pre is not None else proj_fwd(Operand(xq2, mx_of(xq)), sh, w_in, w_in16, b_in, rows=(0, d))
         if kv_pre is not None:
             xkv2, kv = None, kv_pre
         else:
@@ -1041,13 +1086,53 @@ class CrossAttnLN(torch.autograd.Function):
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
         ctx.packed = (AB, ALq, ALk, cu, RL, rows)
         ctx.kv_pre = kv_pre is not None
+        ctx.q_pre = q_pre is not None
+        ctx.slots = slots
         ctx.join_q = join_q
         ctx.params = (w_in, b_in, w_out, b_out, gamma, beta)
         ctx.mark_non_differentiable(*([probs] if probs is not None else []))
         return tag_mx(y.view(B, Lq, d), mx[0] if mx else None), (y32.view(B, Lq, d) if y32 is not None else None), probs
 
     @staticmethod
+    def _backward_shared(ctx, dy, dy32):
+        """q_pre and kv_pre: both projections belong to SharedProjFn nodes.  Left here: LayerNorm / out-projection backward, the
+        attention core's backward (dQ, dK|dV written into the projections' shared gradient buffers, in-projection bias gradients
+        from its column sums), and the residual-path gradient of xq, deposited for the projection's dX GEMM."""
+        xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
+        B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
+        AB, ALq, ALk, cu, RL, rows = ctx.packed
+        dy2 = _contig_bf16(_sum_grads(dy, dy32)).view(B * Lq, d)
+        p_w_in, p_b_in, p_w_out, p_b_out, p_gamma, p_beta = ctx.params
+        sink = GradSink((p_b_in, p_w_out, p_b_out, p_gamma, p_beta))
+        acc = sink.fused
+        ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dy2, g, xq2, gamma, mean, rstd, p, seed, site + 1, b_off * RL,
+                                                   outs=(sink.buf(p_gamma), sink.buf(p_beta), sink.buf(p_b_out)),
+                                                   accumulate=acc, x32=x32v, rows=rows)
+        dw_out = sink.buf(p_w_out)
+        linear_dw(dg, o, dw_out, acc)
+        do = linear_dx(dg, w_out16)
+        sq, skv = ctx.slots
+        dq, dkv = sq.buf(), skv.buf()
+        db_in = sink.buf(p_b_in)
+        folded = attn_bwd(q, kv[:, :d], kv[:, d:], o, do, dq, dkv[:, :d], dkv[:, d:], lse, AB, H, ALq, ALk, hd, kpm, p, seed,
+                          site, b_off, bias_grad=(db_in[:d], db_in[d:], acc), mask_bits=mbits, cu=cu)
+        if not folded:
+            colsum(dq, db_in[:d], acc)
+            colsum(dkv, db_in[d:], acc)
+        dxq = ds
+        if ctx.join_q is not None:
+            ctx.join_q.arrive()
+            ctx.join_q.deposit(ds)            # the projection's dX GEMM adds it in its epilogue
+            dxq = None
+        sink.done()
+        r = sink.ret
+        return (dxq.view(B, Lq, d) if dxq is not None else None, None, None, None, r(db_in), r(dw_out), r(db_out), r(dgamma),
+                r(dbeta)) + (None,) * 8 + (dkv, None, dq, None)
+
+    @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
+        if ctx.q_pre and ctx.kv_pre and ctx.slots is not None:
+            return CrossAttnLN._backward_shared(ctx, dy, dy32)
         xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, Lq, Lk, d, H, hd, p, seed, site, b_off = ctx.cfg
         AB, ALq, ALk, cu, RL, rows = ctx.packed
@@ -1087,12 +1172,12 @@ class CrossAttnLN(torch.autograd.Function):
             if not acc:
                 dw_in[d:].zero_()
             sink.done(skip=(p_w_in,))
-            return (dxq, None, None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8 + (dkv, None)
+            return (dxq, None, None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8 + (dkv, None, None, None)
         linear_dw(dkv, xkv2, dw_in[d:], acc)
         dxkv = linear_dx(dkv, w_in16[d:])
         sink.done()
         return (dxq, None, dxkv.view(B, Lk, d), r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma),
-                r(dbeta)) + (None,) * 10
+                r(dbeta)) + (None,) * 12
 
 
 class GradJoin:
@@ -1136,6 +1221,14 @@ class GradJoin:
 
 
 GRAD_JOIN = _os.environ.get("HRIEMO_GRAD_JOIN", "1") != "0"
+SHARED_PROJ = None         # one N = 3d projection GEMM per shared encoder input (SharedProjFn); HRIEMO_SHARED_PROJ=0: Q and K | V apart
+
+
+def shared_proj():
+    global SHARED_PROJ
+    if SHARED_PROJ is None:
+        SHARED_PROJ = _os.environ.get("HRIEMO_SHARED_PROJ", "1") != "0"
+    return SHARED_PROJ
 
 
 JOIN_SCOPE = 0          # > 0 inside a forward whose outputs ALL depend on both encoder branches (FusionWithEmotionDecoder)
@@ -1146,6 +1239,110 @@ def grad_join(n=2, always=False):
     (a stand-alone CrossModalBlock may be trained on one of its two outputs, and the unused branch's consumers never run), the
     decoder's (its layers are a chain) always"""
     return GradJoin(n) if (GRAD_JOIN and torch.is_grad_enabled() and (always or JOIN_SCOPE > 0)) else None
+
+
+class SharedGrad:
+    """[M, 3d] gradient buffer of one SharedProjFn output, filled by two attention backward launches (dQ by the cross-attention
+    this input queries, dK | dV by the one it serves as keys / values -- different streams), so that the projection's backward
+    reads ONE dY operand.  A slot is a column range of it; the buffer is allocated by whichever slot is asked first."""
+
+    def __init__(self, M, d, device):
+        self.M, self.d, self.device, self.t = M, d, device, None
+
+    def slot(self, c0, c1):
+        return _SharedSlot(self, c0, c1)
+
+    def take(self):
+        t, self.t = self.t, None
+        return t
+
+
+class _SharedSlot:
+    def __init__(self, owner, c0, c1):
+        self.owner, self.c0, self.c1 = owner, c0, c1
+
+    def buf(self):
+        o = self.owner
+        cur = torch.cuda.current_stream(o.device)
+        if o.t is None:
+            o.t = torch.empty((o.M, 3 * o.d), dtype=BF16, device=o.device)
+            o.stream = cur
+        elif o.stream != cur and not CAPTURING:
+            o.t.record_stream(cur)            # written on a second stream as well
+        return o.t[:, self.c0:self.c1]
+
+
+def _report_half(p, sink):
+    """an in-projection weight's gradient is written by TWO SharedProjFn nodes (rows [:d] by the projection of the tensor it
+    queries, rows [d:] by the one it serves as keys / values): the gradient-ready notification goes out with the second"""
+    hook = getattr(p, "_hriemo_grad_ready", None)
+    if not sink.fused or hook is None:
+        return
+    n = _half_reports.get(id(p), 0) + 1
+    if n == 2:
+        _half_reports.pop(id(p), None)
+        hook(p)
+    else:
+        _half_reports[id(p)] = n
+
+
+class SharedProjFn(torch.autograd.Function):
+    """[q | kv][M, 3d] = x . [W_q ; W_kv]^T + [b_q ; b_kv] -- ONE N = 3d GEMM per shared input (reference call
+    sites models/cross_modal_block_tacfn.py:98-104,111-117): each self-attention output is the query input of its own
+    cross-attention (rows [:d] of that module's in_proj_weight) and the key / value input of the other one (rows [d:] of the
+    other module's).  Forward: one GEMM on the row-concatenated bf16 shadow; backward: one K = 3d dX GEMM (the residual-path
+    gradient of x from the cross-attention's LayerNorm arrives through `join` and is added in the epilogue) and the weight
+    gradients from the same [M, 3d] dY buffer.  state_dict is untouched: the parameters stay where the reference has them."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wkv, bkv, sh, join, shared):
+        _require_fp32_masters(wq, bq, wkv, bkv)
+        _require_gpu(x)
+        B, L, d = x.shape
+        x2 = _contig_bf16(x).view(B * L, d)
+        wcat = sh.get_cat(((wq, 0, d), (wkv, d, 3 * d)))
+        bcat = sh.get_cat_vec(((bq, 0, d), (bkv, d, 3 * d)))
+        out = linear_fwd(x2, wcat, bcat)
+        ctx.save_for_backward(x2, wcat)
+        ctx.cfg = (B, L, d)
+        ctx.join, ctx.shared = join, shared
+        ctx.params = (wq, wkv)
+        return out[:, :d], out[:, d:]
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        x2, wcat = ctx.saved_tensors
+        B, L, d = ctx.cfg
+        M = B * L
+        dcat = ctx.shared.take()
+        ok = (dcat is not None and dq is not None and dkv is not None and dq.data_ptr() == dcat.data_ptr()
+              and dkv.data_ptr() == dcat.data_ptr() + 2 * d and dq.stride(0) == 3 * d and dkv.stride(0) == 3 * d)
+        if not ok:                                # gradients that did not come through the shared buffer (or only one of them)
+            dcat = torch.zeros((M, 3 * d), dtype=BF16, device=x2.device)
+            if dq is not None:
+                dcat[:, :d].copy_(dq)
+            if dkv is not None:
+                dcat[:, d:].copy_(dkv)
+        wq, wkv = ctx.params
+        sq, skv = GradSink((wq,)), GradSink((wkv,))
+        dwq = dwkv = None                         # a half whose gradient never arrived leaves its weight's .grad alone (None, like
+        if dq is not None:                        # autograd would for a cross-attention that took no part in the loss)
+            dwq = sq.buf(wq)
+            if not sq.fused:
+                dwq[d:].zero_()
+            linear_dw(dcat[:, :d], x2, dwq[:d], sq.fused)
+        if dkv is not None:
+            dwkv = skv.buf(wkv)
+            if not skv.fused:
+                dwkv[:d].zero_()
+            linear_dw(dcat[:, d:], x2, dwkv[d:], skv.fused)
+        dep = None
+        if ctx.join is not None:
+            _, dep = ctx.join.arrive()
+        dx = linear_dx(dcat, wcat, epi=3, aux=dep.view(M, d)) if dep is not None else linear_dx(dcat, wcat)
+        _report_half(wq, sq)
+        _report_half(wkv, skv)
+        return dx.view(B, L, d), (sq.ret(dwq) if dwq is not None else None), None, (skv.ret(dwkv) if dwkv is not None else None), None, None, None, None
 
 
 class KVProjFn(torch.autograd.Function):
@@ -1321,6 +1518,7 @@ class BetaGateFn(torch.autograd.Function):
         ctx.save_for_backward(xa, xt, An, Tn, mean_a, rstd_a, mean_t, rstd_t, gin, a_pool, t_pool, cnt, hid, w, w1_16,
                               w2_16, ga, gt, kpm_a, kpm_t, h_a32, h_t32)
         ctx.cfg = (B, La, Lt, L, d)
+        ctx.params = (ga, ba, gt, bt, w1, b1, w2, b2)
         return H, beta
 
     @staticmethod
@@ -1332,6 +1530,11 @@ class BetaGateFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         st = _stream()
         L_ = _lib.lib()
+        p_ga, p_ba, p_gt, p_bt, p_w1, p_b1, p_w2, p_b2 = ctx.params
+        # parameter gradients go straight into .grad when the parameters were opted in (dp.GradBuckets): no autograd accumulate
+        # launches on the serial chain between the decoder's and the encoder's backward
+        sink = GradSink(ctx.params)
+        acc = sink.fused
         dH2 = _contig_bf16(dH) if dH is not None else torch.zeros((B, L, d), dtype=BF16, device=dev)
         dbeta2 = dbeta.contiguous().float() if dbeta is not None else None
         part = torch.empty((B, L_.hriemo_pool_chunks(L), d), **f32)
@@ -1339,44 +1542,55 @@ class BetaGateFn(torch.autograd.Function):
         dpre = torch.empty((B, d), dtype=BF16, device=dev)
         _lib.call("hriemo_gate_dpre", _p(part), L, _p(dbeta2), _p(w), _p(dpre), B, d, st)
         Hd = hid.shape[1]
-        dw2 = torch.empty((d, Hd), **f32)
-        linear_dw(dpre, hid, dw2)
-        db2 = torch.empty(d, **f32)
-        colsum(dpre, db2)
+        dw2 = sink.buf(p_w2)
+        linear_dw(dpre, hid, dw2, acc)
+        db2 = sink.buf(p_b2)
+        colsum(dpre, db2, acc)
         dhid = linear_dx(dpre, w2_16, epi=2, aux=hid)
-        dw1 = torch.empty((Hd, 4 * d), **f32)
-        linear_dw(dhid, gin, dw1)
-        db1 = torch.empty(Hd, **f32)
-        colsum(dhid, db1)
+        dw1 = sink.buf(p_w1)
+        linear_dw(dhid, gin, dw1, acc)
+        db1 = sink.buf(p_b1)
+        colsum(dhid, db1, acc)
         dgin = linear_dx(dhid, w1_16)
         da, dt = torch.empty((B, d), **f32), torch.empty((B, d), **f32)
         _lib.call("hriemo_gate_input_bwd", _p(dgin), _p(a_pool), _p(t_pool), _p(cnt), _p(da), _p(dt), B, d, st)
         dxa = torch.empty((B, La, d), dtype=BF16, device=dev)
         dxt = torch.empty((B, Lt, d), dtype=BF16, device=dev)
-        sa, st_ = torch.empty((2, d), **f32), torch.empty((2, d), **f32)
-        ws = workspace(max(L_.hriemo_ln_pool_bwd_workspace_bytes(B, La, d),
-                           L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d)), dev, slot=1)
+        dga, dba, dgt, dbt = sink.buf(p_ga), sink.buf(p_ba), sink.buf(p_gt), sink.buf(p_bt)
+        # LayerNorm-affine gradients: finished by the launch-boundary reduce when they accumulate into .grad inside backward (the
+        # kernel's partial sums then live in a buffer of their own instead of the shared workspace), else by the call's own reduce
+        defer = acc and DEFER_REDUCE and _in_backward()
+        nba, nbt = L_.hriemo_ln_pool_bwd_workspace_bytes(B, La, d), L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d)
+
+        def ln_pool_bwd(is_a, dpool, kpm, x, x32, gamma, mean, rstd, dx, dgam, dbet, Lx, nbytes):
+            if defer:
+                wsx = torch.empty(nbytes // 4 + 16, **f32)
+                _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), is_a, _p(dpool), _p(kpm), _p(x), _p(x32), _p(gamma), _p(mean),
+                          _p(rstd), _p(dx), None, None, 1, B, Lx, d, _p(wsx), _stream())
+                _deferred.add(wsx, 2 * d, B * ((Lx + 31) // 32), d, 2, [dgam, dbet], True)
+            else:
+                wsx = workspace(nbytes, dev, slot=1)
+                _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), is_a, _p(dpool), _p(kpm), _p(x), _p(x32), _p(gamma), _p(mean),
+                          _p(rstd), _p(dx), _p(dgam), _p(dbet), int(acc), B, Lx, d, _p(wsx), _stream())
+
         main = torch.cuda.current_stream(dev)
         side = side_stream(dev) if GATE_TWO_STREAMS else None
         if side is not None and side != main:
             # text on the side stream (its own workspace there), audio on this one; joined before the gradients are handed back
             fork(side, main)
             with torch.cuda.stream(side):
-                ws_t = workspace(L_.hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d), dev, slot=1)
-                _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
-                          _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws_t), _stream())
-            _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a),
-                      _p(rstd_a), _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
+                ln_pool_bwd(0, dt, kpm_t, xt, h_t32, gt, mean_t, rstd_t, dxt, dgt, dbt, Lt, nbt)
+            ln_pool_bwd(1, da, kpm_a, xa, h_a32, ga, mean_a, rstd_a, dxa, dga, dba, La, nba)
             main.wait_stream(side)
             if not CAPTURING:
-                for t_ in (dH2, w, dt, dxt, st_):
+                for t_ in (dH2, w, dt, dxt, dgt, dbt):
                     share(t_, side)
         else:
-            _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 1, _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a),
-                      _p(rstd_a), _p(dxa), _p(sa[0]), _p(sa[1]), B, La, d, _p(ws), st)
-            _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), 0, _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t),
-                      _p(rstd_t), _p(dxt), _p(st_[0]), _p(st_[1]), B, Lt, d, _p(ws), st)
-        return dxa, None, dxt, None, sa[0], sa[1], st_[0], st_[1], dw1, db1, dw2, db2, None, None, None
+            ln_pool_bwd(1, da, kpm_a, xa, h_a32, ga, mean_a, rstd_a, dxa, dga, dba, La, nba)
+            ln_pool_bwd(0, dt, kpm_t, xt, h_t32, gt, mean_t, rstd_t, dxt, dgt, dbt, Lt, nbt)
+        sink.done()
+        r = sink.ret
+        return dxa, None, dxt, None, r(dga), r(dba), r(dgt), r(dbt), r(dw1), r(db1), r(dw2), r(db2), None, None, None
 
 
 class LegacyBetaGateFn(torch.autograd.Function):
@@ -1447,7 +1661,7 @@ class LegacyBetaGateFn(torch.autograd.Function):
         dhid = torch.empty((B, Hd), dtype=BF16, device=dev)
         dw2 = torch.empty((1, Hd), **f32)
         db2 = torch.empty(1, **f32)
-        _lib.call("hriemo_rowdot_bwd", _p(dpre), _p(hid), None, _p(w2f), _p(dhid), _p(dw2), _p(db2), B, Hd, st)
+        _lib.call("hriemo_rowdot_bwd", _p(dpre), _p(hid), None, _p(w2f), _p(dhid), _p(dw2), _p(db2), 0, B, Hd, st)
         dhid = dhid * (hid > 0)                                                            # ReLU mask, [B,h]-sized plumbing
         dw1 = torch.empty((Hd, 4 * d), **f32)
         linear_dw(dhid, gin, dw1)
@@ -1571,15 +1785,18 @@ class ExpandFn(torch.autograd.Function):
         src = q.detach().float().contiguous()
         _lib.call("hriemo_expand_rows", _p(src), _p(out), B, Ne * d, _stream())
         ctx.cfg = (B, Ne, d)
+        ctx.params = (q,)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         B, Ne, d = ctx.cfg
         g = _contig_bf16(dout).view(B, Ne * d)
-        dq = torch.empty(Ne * d, dtype=torch.float32, device=g.device)
-        colsum(g, dq)
-        return dq.view(Ne, d), None
+        sink = GradSink(ctx.params)
+        dq = sink.buf(ctx.params[0])
+        colsum(g, dq.view(Ne * d), sink.fused)
+        sink.done(after_flush=ctx.params)
+        return sink.ret(dq), None
 
 
 class RowDotFn(torch.autograd.Function):
@@ -1599,6 +1816,7 @@ class RowDotFn(torch.autograd.Function):
         _lib.call("hriemo_rowdot_fwd", _p(z2), _p(z32v), _p(wf), _p(bf), _p(out), B * Ne, d, _stream())
         ctx.save_for_backward(z2, z32v, wf)
         ctx.cfg = (B, Ne, d)
+        ctx.params = (w, b)
         return out.view(B, Ne)
 
     @staticmethod
@@ -1607,7 +1825,8 @@ class RowDotFn(torch.autograd.Function):
         B, Ne, d = ctx.cfg
         dl2 = dl.contiguous().float().view(-1)
         dz = torch.empty((B * Ne, d), dtype=BF16, device=z2.device)
-        dw = torch.empty((1, d), dtype=torch.float32, device=z2.device)
-        db = torch.empty(1, dtype=torch.float32, device=z2.device)
-        _lib.call("hriemo_rowdot_bwd", _p(dl2), _p(z2), _p(z32v), _p(wf), _p(dz), _p(dw), _p(db), B * Ne, d, _stream())
-        return dz.view(B, Ne, d), None, dw, db
+        sink = GradSink(ctx.params)
+        dw, db = sink.buf(ctx.params[0]), sink.buf(ctx.params[1])
+        _lib.call("hriemo_rowdot_bwd", _p(dl2), _p(z2), _p(z32v), _p(wf), _p(dz), _p(dw), _p(db), int(sink.fused), B * Ne, d, _stream())
+        sink.done()
+        return dz.view(B, Ne, d), None, sink.ret(dw), sink.ret(db)

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restric
 }
 // dZ[r,:] = dl[r]*w ; dw[e] = sum_r dl[r] z[r,e] ; db = sum_r dl[r]   (M is small: B*N_e)
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ Z32, const float* __restrict__ w,
-                                                         bf16_t* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d) {
+                                                         bf16_t* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d,
+                                                         int accumulate) {
   __shared__ float red[8][33];
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][c];
-    dw[col] = t;
+    dw[col] = accumulate ? dw[col] + t : t;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     if (threadIdx.x == 0) {
       float t = 0.f;
       for (int k = 0; k < 8; ++k) t += red[k][0];
-      db[0] = t;
+      db[0] = accumulate ? db[0] + t : t;
     }
   }
 }
@@ -930,10 +931,10 @@ extern "C" int hriemo_rowdot_fwd(const void* Z, const float* Z32, const float* w
   HRIEMO_LAUNCH_CHECK("rowdot_fwd_kernel");
   return 0;
 }
-extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db, int M, int d,
-                                 hipStream_t st) {
+extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db,
+                                 int accumulate, int M, int d, hipStream_t st) {
   if (check_rows(M, d)) return 1;
-  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(256), 0, st, dl, (const bf16_t*)Z, Z32, w, (bf16_t*)dZ, dw, db, M, d);
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(256), 0, st, dl, (const bf16_t*)Z, Z32, w, (bf16_t*)dZ, dw, db, M, d, accumulate);
   HRIEMO_LAUNCH_CHECK("rowdot_bwd_kernel");
   return 0;
 }
@@ -1198,9 +1199,9 @@ extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return
 
 extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                                   const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
-                                  float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hipStream_t st) {
+                                  float* dgamma, float* dbeta, int accumulate, int B, int L, int d, float* workspace, hipStream_t st) {
   if (check_rows(B * L, d)) return 1;
-  HRIEMO_CHECK(workspace != nullptr && Lf <= L, "ln_pool_bwd: bad arguments");
+  HRIEMO_CHECK(workspace != nullptr && Lf <= L && (dgamma == nullptr) == (dbeta == nullptr), "ln_pool_bwd: bad arguments");
   const int nc = (L + 31) / 32;
   hriemo_prof_begin(HP_ROWOPS, st);
 #define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), 2 * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
@@ -1208,9 +1209,10 @@ extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (2.0 * B * L + (double)B * Lf) * d * 2);
+  if (dgamma == nullptr) return 0;          // partial sums stay in `workspace` ([B * ceil(L/32)][2d]) for the launch-boundary reduce
   float* scratch = workspace + (long)B * nc * 2 * d;
   ReduceOut ro; ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = nullptr;
-  launch_colreduce(workspace, (long)2 * d, B * nc, ro, d, 2, 0, scratch, st);
+  launch_colreduce(workspace, (long)2 * d, B * nc, ro, d, 2, accumulate, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
   return 0;
 }

@@ -42,10 +42,18 @@ class CrossModalBlock(nn.Module):
                                      mha.out_proj.bias, ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed, site,
                                      self.batch_offset, need_w)
 
-    def _cross(self, xq, xq32, xkv, mha, ln, kpm, p, seed, site, need_w, kv_pre=None, join_q=None):
+    def _cross(self, xq, xq32, xkv, mha, ln, kpm, p, seed, site, need_w, kv_pre=None, join_q=None, q_pre=None, slots=None):
         return _ops.CrossAttnLN.apply(xq, xq32, xkv, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
                                       mha.out_proj.bias, ln.weight, ln.bias, self._sh, self.n_heads, kpm, p, seed,
-                                      site, self.batch_offset, need_w, kv_pre, join_q)
+                                      site, self.batch_offset, need_w, kv_pre, join_q, q_pre, slots)
+
+    def _shared_proj(self, x, mha_q, mha_kv, join):
+        """[Q of the cross-attention `x` queries | K, V of the one it serves] from ONE N = 3d GEMM (_ops.SharedProjFn);
+        -> (q, kv, SharedGrad the two attention backwards write dQ and dK | dV into)"""
+        sg = _ops.SharedGrad(x.shape[0] * x.shape[1], x.shape[2], x.device)
+        q, kv = _ops.SharedProjFn.apply(x, mha_q.in_proj_weight, mha_q.in_proj_bias, mha_kv.in_proj_weight, mha_kv.in_proj_bias,
+                                        self._sh, join, sg)
+        return q, kv, sg
 
     def _kv(self, xkv, mha, join):
         """K | V projection of a cross-attention as its own node (_ops.KVProjFn): the gradient it returns for `xkv` meets the
@@ -88,7 +96,48 @@ class CrossModalBlock(nn.Module):
         ja = jt = None
         use_kv = not fp32
         join_for = lambda x: _ops.grad_join(2) if (use_kv and x.requires_grad) else None          # noqa: E731
-        if side is None:
+        d = a.shape[2]
+        shared = use_kv and _ops.shared_proj() and _ops.gemm_mode() == "bf16"
+        if shared and side is None:
+            a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
+            t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
+            ja, jt = join_for(a_s), join_for(t_s)
+            q_a2t, kv_t2a, sga = self._shared_proj(a_s, self.attn_a2t, self.attn_t2a, ja)
+            q_t2a, kv_a2t, sgt = self._shared_proj(t_s, self.attn_t2a, self.attn_a2t, jt)
+            x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
+                                        kv_a2t, ja, q_a2t, (sga.slot(0, d), sgt.slot(d, 3 * d)))                   # :98-105
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)
+            x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
+                                        kv_t2a, jt, q_t2a, (sgt.slot(0, d), sga.slot(d, 3 * d)))                   # :111-118
+            t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None)
+        elif shared:
+            # two streams, one GEMM per shared input: each branch projects its own self-attention output to [Q | K, V] on its own
+            # stream (no dependence on the other branch yet), THEN the branches exchange the K | V halves and run the cores
+            _ops.fork(side, main)
+            for x_ in (t, t32, kpm_t, kpm_a):
+                _ops.share(x_, side)
+            with torch.cuda.stream(side):
+                t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
+                jt = join_for(t_s)
+                q_t2a, kv_a2t, sgt = self._shared_proj(t_s, self.attn_t2a, self.attn_a2t, jt)
+            a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
+            ja = join_for(a_s)
+            q_a2t, kv_t2a, sga = self._shared_proj(a_s, self.attn_a2t, self.attn_t2a, ja)
+            main.wait_stream(side)
+            _ops.fork(side, main)
+            _ops.share(kv_a2t, main)
+            _ops.share(kv_t2a, side)
+            with torch.cuda.stream(side):
+                x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
+                                            kv_t2a, jt, q_t2a, (sgt.slot(0, d), sga.slot(d, 3 * d)))
+                t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None)
+            x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
+                                        kv_a2t, ja, q_a2t, (sga.slot(0, d), sgt.slot(d, 3 * d)))
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)
+            main.wait_stream(side)
+            for x_ in (t_cm, t_cm32, w_t, w_t2a):
+                _ops.share(x_, main)
+        elif side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
             t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92
             ja, jt = join_for(a_s), join_for(t_s)

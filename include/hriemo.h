@@ -172,8 +172,9 @@ int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, uns
 int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
 int hriemo_rowdot_fwd(const void* Z, const float* Z32, const float* w, const float* b, float* out, int M, int d,
                       hriemo_stream_t stream);                                     /* emotion_decoder.py:155 */
-int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db, int M, int d,
-                      hriemo_stream_t stream);
+/* dw[d], db[1]: overwritten, or added to when accumulate != 0 (gradients accumulated straight into .grad) */
+int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db, int accumulate,
+                      int M, int d, hriemo_stream_t stream);
 
 /* ---- beta gate (models/beta_gate_tacfn.py:68-118): LayerNorm + masked mean-pool (:6-24,79-84),
  * gate input [a,t,|a-t|,a*t] (:87-89), w = sigmoid(MLP), beta = mean(w) (:92-95), fuse over the first
@@ -241,7 +242,9 @@ int hriemo_debug_hog(int blocks, int micros, float* sink, hriemo_stream_t stream
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
 int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                        const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
-                       float* dgamma, float* dbeta, int B, int L, int d, float* workspace, hriemo_stream_t stream);
+                       float* dgamma, float* dbeta, int accumulate, int B, int L, int d, float* workspace, hriemo_stream_t stream);
+/* (dgamma / dbeta: overwritten, or added to when accumulate != 0; both NULL: the per-block partial sums stay in `workspace`, rows
+ * [B * ceil(L/32)] of [dgamma | dbeta] (2d floats each), for hriemo_colreduce_batch at the end of backward) */
 
 /* ---- fp32-tolerance inference mode (csrc/fp32mode.hip; host side hri-emo_amd/_fp32.py, HRIEMO_PRECISION=fp32).
  * The reference's modules are fp32 nn.Modules throughout (models/cross_modal_block_tacfn.py:70-125, beta_gate_tacfn.py:68-118,

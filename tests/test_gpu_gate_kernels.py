@@ -201,9 +201,9 @@ def test_gate_backward_chain_through_c_abi(lib, B, La, Lt, d, masked, twin):
     wsb = max(lib.lib().hriemo_ln_pool_bwd_workspace_bytes(B, La, d), lib.lib().hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d))
     ws = f32(wsb // 4 + 16)
     lib.call("hriemo_ln_pool_bwd", P(dH_d), L, P(w_d), 1, P(da), P(ma_d), P(xa_d), P(xa32_d), P(ga_d), P(mean_a), P(rstd_a), P(dxa),
-             P(dga), P(dba), B, La, d, P(ws), ST())
+             P(dga), P(dba), 0, B, La, d, P(ws), ST())
     lib.call("hriemo_ln_pool_bwd", P(dH_d), L, P(w_d), 0, P(dt), P(mt_d), P(xt_d), P(xt32_d), P(gt_d), P(mean_t), P(rstd_t), P(dxt),
-             P(dgt), P(dbt), B, Lt, d, P(ws), ST())
+             P(dgt), P(dbt), 0, B, Lt, d, P(ws), ST())
     # dX: bf16 output of O(1) values; everything upstream of it is fp32 here
     for name, got, ref in (("dxa", dxa, src_a.grad), ("dxt", dxt, src_t.grad)):
         err = (got.float().cpu() - ref).abs().max().item()

@@ -734,6 +734,49 @@ def test_shared_activation_gradients_joined_in_the_gemm_epilogue(H, monkeypatch)
         kv.float().sum().backward()          # the join's other consumer never arrives
 
 
+@pytest.mark.parametrize("two_streams", [True, False])
+def test_shared_input_projection_equals_separate_projections(H, monkeypatch, two_streams):
+    """_ops.SharedProjFn: ONE N = 3d GEMM per self-attention output ([Q of its own cross-attention | K, V of the other one],
+    models/cross_modal_block_tacfn.py:98-104,111-117) instead of a Q and a K|V launch, one K = 3d dX GEMM in backward.  Same
+    outputs (bit for bit: the GEMM tiles do not depend on N) and the same gradients (one bf16 rounding of the summed activation
+    gradient apart) as the separate projections (HRIEMO_SHARED_PROJ=0); the state_dict is untouched; also a stand-alone block
+    trained on one output only (one of the two gradient halves never arrives)."""
+    from hri_emo_amd import _ops
+    from hri_emo_amd.train import fusion_step_loss
+    monkeypatch.setattr(_ops, "TWO_STREAMS", two_streams)
+    torch.manual_seed(11)
+    m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=5, n_heads=8, dropout=0.0).cuda().train()
+    keys = list(m.state_dict().keys())
+    h_a, h_t, m_a, m_t = _rand_batch(4, 90, 36, 256, 31)
+    y = (torch.rand(4, 5, generator=torch.Generator().manual_seed(4)) < 0.3).float().cuda()
+    outs, grads = [], []
+    for on in (True, False):
+        monkeypatch.setattr(_ops, "SHARED_PROJ", on)
+        m.zero_grad(set_to_none=True)
+        logits, beta, z = m(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+        fusion_step_loss(logits, beta, y).backward()
+        outs.append((logits.detach().clone(), beta.detach().clone(), z.detach().clone()))
+        grads.append({n: p.grad.detach().float().clone() for n, p in m.named_parameters()})
+    assert list(m.state_dict().keys()) == keys
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    worst = max(float((grads[0][n] - grads[1][n]).norm() / grads[1][n].norm().clamp_min(1e-20)) for n in grads[0])
+    assert worst <= 1e-2, worst
+    monkeypatch.setattr(_ops, "SHARED_PROJ", True)
+    blk = H.CrossModalBlock(256, 8, 0.0).cuda().train()
+    ref = H.CrossModalBlock(256, 8, 0.0).cuda().train()
+    ref.load_state_dict(blk.state_dict())
+    oa, ot = blk(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    oa.float().pow(2).mean().backward()
+    monkeypatch.setattr(_ops, "SHARED_PROJ", False)
+    ra, rt = ref(cu(h_a), cu(h_t), cu(m_a), cu(m_t))
+    ra.float().pow(2).mean().backward()
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert float((p.grad - q.grad).norm()) <= 1e-2 * max(float(q.grad.norm()), 1e-20), n
+
+
 def test_partial_fine_tuning_with_a_frozen_cross_attention(H, monkeypatch):
     """a join is only created where both consumers of a shared activation get a backward node.  Layer 0 frozen except
     its audio->text cross-attention, inputs without gradient: the t2a K|V projection node never exists, and the a2t core must
