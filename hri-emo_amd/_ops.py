@@ -406,6 +406,15 @@ def linear_dw(dy, x, out, accumulate=False):
     gemm(1, 1, N, K, M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True, accumulate=accumulate)
 
 
+def linear_dw_split(dy, x, out, out2, split, accumulate=False):
+    """[out ; out2] (+)= dY[M,N]^T . X[M,K]: rows [0, split) of the [N, K] result to `out`, the rest to `out2` (one launch)"""
+    M, N = dy.shape
+    K = x.shape[1]
+    ws = workspace(64 << 20, out.device)
+    _lib.call("hriemo_gemm_bf16_split", 1, 1, N, K, M, _p(dy), dy.stride(0), _p(x), x.stride(0), _p(out), out.stride(0), _p(out2),
+              out2.stride(0), split, int(accumulate), _p(ws), ws.numel() * 4, _stream())
+
+
 # ---- MX-fp8 operand path (forward projection / FFN GEMMs; include/hriemo.h "MX-fp8 operand path")
 GEMM_MODE = None           # 'bf16' | 'mx_fp8'; read from HRIEMO_GEMM at first use, set_gemm_mode() changes it at run time
 
@@ -1298,6 +1307,7 @@ class SharedProjFn(torch.autograd.Function):
     def forward(ctx, x, wq, bq, wkv, bkv, sh, join, shared):
         _require_fp32_masters(wq, bq, wkv, bkv)
         _require_gpu(x)
+        ctx.set_materialize_grads(False)      # a half nobody differentiated must arrive as None, not as zeros
         B, L, d = x.shape
         x2 = _contig_bf16(x).view(B * L, d)
         wcat = sh.get_cat(((wq, 0, d), (wkv, d, 3 * d)))
@@ -1315,6 +1325,8 @@ class SharedProjFn(torch.autograd.Function):
         B, L, d = ctx.cfg
         M = B * L
         dcat = ctx.shared.take()
+        if dq is None and dkv is None:
+            return (None,) * 8
         ok = (dcat is not None and dq is not None and dkv is not None and dq.data_ptr() == dcat.data_ptr()
               and dkv.data_ptr() == dcat.data_ptr() + 2 * d and dq.stride(0) == 3 * d and dkv.stride(0) == 3 * d)
         if not ok:                                # gradients that did not come through the shared buffer (or only one of them)
@@ -1330,12 +1342,17 @@ class SharedProjFn(torch.autograd.Function):
             dwq = sq.buf(wq)
             if not sq.fused:
                 dwq[d:].zero_()
-            linear_dw(dcat[:, :d], x2, dwq[:d], sq.fused)
         if dkv is not None:
             dwkv = skv.buf(wkv)
             if not skv.fused:
                 dwkv[:d].zero_()
-            linear_dw(dcat[:, d:], x2, dwkv[d:], skv.fused)
+        if dwq is not None and dwkv is not None and sq.fused == skv.fused:
+            linear_dw_split(dcat, x2, dwq[:d], dwkv[d:], d, sq.fused)        # one 3d x d x M weight-gradient GEMM, two destinations
+        else:
+            if dwq is not None:
+                linear_dw(dcat[:, :d], x2, dwq[:d], sq.fused)
+            if dwkv is not None:
+                linear_dw(dcat[:, d:], x2, dwkv[d:], skv.fused)
         dep = None
         if ctx.join is not None:
             _, dep = ctx.join.arrive()

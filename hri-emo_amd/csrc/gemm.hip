@@ -424,14 +424,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
 // (Tried in round 2: no separate launch at all -- the wave that stores the last slab of its 64-column sub-tile reduces it,
 // arrival counters in device memory.  The slabs come from other XCDs, so the hand-over needs agent-scope release/acquire
 // fences, i.e. an L2 write-back and invalidate per wave: 156 us instead of 56 for the 768x768x25600 weight gradient.  Dropped.)
+// Rows >= split_m go to a second matrix (C2, row split_m first): the weight gradient of a projection whose weight rows live in
+// two parameters (SharedProjFn: rows [0, d) of one in_proj_weight, rows [d, 3d) of another one) comes out of ONE GEMM.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long ldc, int M, int N,
-                                                            int splitk, int accumulate) {
+                                                            int splitk, int accumulate, float* __restrict__ C2, long ldc2, int split_m) {
   const long nv = (long)M * N / 4, slab = (long)M * N;
   for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
     const long e = v * 4;
     const int m = (int)(e / N), n = (int)(e - (long)m * N);
     const float* src = ws + e;
-    float* dst = C + (long)m * ldc + n;
+    float* dst = m < split_m ? C + (long)m * ldc + n : C2 + (long)(m - split_m) * ldc2 + n;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     if (accumulate) c = *(const f32x4*)dst;
     f32x4 s = *(const f32x4*)src;
@@ -563,8 +565,11 @@ extern "C" int hriemo_gemm_colsum_rows(int ta, int tb, int M, int N, int K) {
 
 static int gemm_impl(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                      void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
-                     long ldaux, int accumulate, float* workspace, long workspace_bytes, float* colsum_partials, hipStream_t st) {
+                     long ldaux, int accumulate, float* workspace, long workspace_bytes, float* colsum_partials, hipStream_t st,
+                     void* C2 = nullptr, long ldc2 = 0, int split_m = 0) {
   HRIEMO_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
+  HRIEMO_CHECK(C2 == nullptr || (c_is_f32 && split_m > 0 && split_m < M && ldc2 % 4 == 0 && ((uintptr_t)C2 % 16) == 0),
+               "gemm: a split output needs fp32 results, 0 < split_m < M and a 16-byte aligned second matrix");
   HRIEMO_CHECK(!(ta == 1 && tb == 0), "gemm: layout (ta=1,tb=0) is not used by this path and not built");
   HRIEMO_CHECK(N % 8 == 0, "gemm: N=%d must be a multiple of 8", N);
   HRIEMO_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % (c_is_f32 ? 4 : 8) == 0, "gemm: leading dims must keep 16-byte alignment");
@@ -607,6 +612,14 @@ static int gemm_impl(int ta, int tb, int M, int N, int K, const void* A, long ld
     a.tiles_m = (M + kCfg[cfg].bm - 1) / kCfg[cfg].bm; a.tiles_n = (N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   }
   a.splitk = splitk; a.k_per_split = kper;
+  if (C2 != nullptr && splitk == 1) {
+    // the split is applied by the split-K reduce; a problem that is not split along K runs as two launches instead
+    const char* A2 = (const char*)A + (size_t)split_m * 2;      // ta == 1: A is [K][M], its column m is output row m
+    HRIEMO_CHECK(ta == 1, "gemm: a split output without split-K is built for the weight-gradient layout only");
+    int rc = gemm_impl(ta, tb, split_m, N, K, A, lda, B, ldb, C, ldc, 1, nullptr, 0, nullptr, 0, accumulate, workspace, workspace_bytes, nullptr, st);
+    if (rc != 0) return rc;
+    return gemm_impl(ta, tb, M - split_m, N, K, A2, lda, B, ldb, C2, ldc2, 1, nullptr, 0, nullptr, 0, accumulate, workspace, workspace_bytes, nullptr, st);
+  }
 
   const int cls = ta ? HP_GEMM_TN : (tb ? HP_GEMM_NN : HP_GEMM_NT);
   hriemo_prof_begin(cls, st);
@@ -623,7 +636,7 @@ static int gemm_impl(int ta, int tb, int M, int N, int K, const void* A, long ld
     int grid = (int)((nv + 255) / 256);
     if (grid > 16 * hriemo_num_cus()) grid = 16 * hriemo_num_cus();
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, workspace, (float*)C, ldc, M, N, splitk,
-                       accumulate);
+                       accumulate, (float*)C2, ldc2, C2 != nullptr ? split_m : M);
     HRIEMO_LAUNCH_CHECK("splitk_reduce_kernel");
   }
   hriemo_prof_end(cls, st, 2.0 * M * N * K);
@@ -635,6 +648,14 @@ extern "C" int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void*
                                 long ldaux, int accumulate, float* workspace, long workspace_bytes, hipStream_t st) {
   return gemm_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, c_is_f32, bias, epilogue, aux, ldaux, accumulate, workspace, workspace_bytes,
                    nullptr, st);
+}
+// fp32 output whose rows [0, split_m) go to C and rows [split_m, M) to C2 (row split_m = row 0 of C2); ta / tb as hriemo_gemm_bf16
+extern "C" int hriemo_gemm_bf16_split(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                                      void* C, long ldc, void* C2, long ldc2, int split_m, int accumulate, float* workspace,
+                                      long workspace_bytes, hipStream_t st) {
+  HRIEMO_CHECK(C2 != nullptr, "gemm_split: second output missing");
+  return gemm_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, nullptr, 0, nullptr, 0, accumulate, workspace, workspace_bytes, nullptr, st,
+                   C2, ldc2, split_m);
 }
 extern "C" int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                                        void* C, long ldc, const void* aux, long ldaux, float* colsum_partials, hipStream_t st) {

@@ -44,6 +44,13 @@ int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long ld
                      void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
                      long ldaux, int accumulate, float* workspace, long workspace_bytes, hriemo_stream_t stream);
 
+/* hriemo_gemm_bf16 with an fp32 result written to TWO matrices: rows [0, split_m) of the [M, N] result to C, rows [split_m, M) to
+ * C2 (from its row 0).  The weight gradient of a projection whose weight rows belong to two parameters -- one N = 3d GEMM per
+ * shared input: rows [0, d) are the Q rows of one nn.MultiheadAttention.in_proj_weight, rows [d, 3d) the K | V rows of another
+ * (models/cross_modal_block_tacfn.py:98-104,111-117) -- in one launch.  accumulate as in hriemo_gemm_bf16. */
+int hriemo_gemm_bf16_split(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                           void* C2, long ldc2, int split_m, int accumulate, float* workspace, long workspace_bytes,
+                           hriemo_stream_t stream);
 /* C[M,N] (bf16) = (A . B) * (aux > 0) as hriemo_gemm_bf16 with epilogue 2, plus the column sums of the stored (masked, rounded)
  * C as per-row-block partials [hriemo_gemm_colsum_rows(ta,tb,M,N,K)][N] fp32 -- summed over rows (hriemo_colreduce_batch) they
  * are the bias gradient of the FIRST Linear of a feed-forward block (dh = (dy . W2) * relu'(h), db1 = colsum(dh);

@@ -102,6 +102,25 @@ def test_gemm_tn_splitk_weight_gradient_shapes(ops, M, N, K):
     assert float((r1 - want).abs().max()) <= 2e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,split", [(25600, 2304, 768, 768), (8192, 2304, 768, 768), (96, 384, 128, 128), (4096, 768, 256, 512)])
+def test_gemm_tn_split_output(ops, M, N, K, split):
+    """hriemo_gemm_bf16_split: one weight-gradient GEMM whose result rows go to two matrices (the Q rows of one in_proj_weight and
+    the K | V rows of another one, _ops.SharedProjFn).  Exact on integers against torch, with and without accumulate, into row
+    slices of wider parameters-like buffers; the small shape takes the path without split-K (two launches inside the library)."""
+    dY, X = ints((M, N), -2, 3, seed=31), ints((M, K), -2, 3, seed=32)
+    ref = dY.t().double() @ X.double()
+    dYd, Xd = dY.cuda().bfloat16(), X.cuda().bfloat16()
+    pa = torch.zeros((N, K), dtype=torch.float32, device="cuda")          # parameter A: its rows [0, split) are written
+    pb = torch.zeros((N, K), dtype=torch.float32, device="cuda")          # parameter B: its rows [split, N) are written
+    for rep in range(2):
+        ops.linear_dw_split(dYd, Xd, pa[:split], pb[split:], split, accumulate=True)
+        assert torch.equal(pa[:split].double().cpu(), (rep + 1) * ref[:split])
+        assert torch.equal(pb[split:].double().cpu(), (rep + 1) * ref[split:])
+    assert float(pa[split:].abs().max()) == 0.0 and float(pb[:split].abs().max()) == 0.0
+    ops.linear_dw_split(dYd, Xd, pa[:split], pb[split:], split, accumulate=False)
+    assert torch.equal(pa[:split].double().cpu(), ref[:split]) and torch.equal(pb[split:].double().cpu(), ref[split:])
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(200, 136, 96), (1000, 768, 256), (25600, 3072, 768), (8192, 3072, 768), (384, 2048, 768)])
 def test_gemm_masked_dx_with_column_sums(ops, cfg, M, N, K):

@@ -1010,3 +1010,28 @@ def test_two_gpus_rccl_exchange_equals_single_rank(H):
     for name, flat in res.items():
         got = torch.from_numpy(flat)
         assert _rel(got, ref) < (1e-2 if "bf16" in name else 2e-3), (name, _rel(got, ref))
+
+
+def test_device_prefetcher_overlapped_copies_hand_out_the_right_batches(H):
+    """hri_emo_amd.data.DevicePrefetcher (the trainer's .to(device) at the top of every step,
+    scripts/fusion/train_fusion_seq_level_decoder.py:306-308, as pinned double buffers on a copy stream): with ring slots being
+    reused (12 batches through depth 2 and 3), pageable and pinned sources, each batch must arrive intact while the consumer
+    stream is kept busy between hand-outs."""
+    from hri_emo_amd.data import DevicePrefetcher
+    g = torch.Generator().manual_seed(3)
+    host = []
+    for i in range(12):
+        a_ = torch.randn(4, 50, 64, generator=g)
+        host.append((a_.pin_memory() if i % 2 else a_, torch.randn(4, 20, 64, generator=g), torch.rand(4, 50) < 0.3, None, torch.full((4, 3), float(i))))
+    busy = torch.randn(2048, 2048, device="cuda")
+    for depth in (2, 3):
+        n = 0
+        for i, b in enumerate(DevicePrefetcher(host, "cuda", depth=depth, dtypes=(torch.bfloat16, torch.bfloat16, None, None, None))):
+            assert b[3] is None and b[0].is_cuda and b[0].dtype == torch.bfloat16
+            keep = [t.clone() for t in b if t is not None]
+            for _ in range(3):
+                busy = (busy @ busy).clamp(-1, 1)          # the "step": the next batch's copy runs beside it
+            assert torch.equal(keep[0].cpu(), host[i][0].bfloat16()) and torch.equal(keep[1].cpu(), host[i][1].bfloat16())
+            assert torch.equal(keep[2].cpu(), host[i][2]) and torch.equal(keep[3].cpu(), host[i][4])
+            n += 1
+        assert n == 12
