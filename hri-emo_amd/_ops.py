@@ -1214,8 +1214,7 @@ class GradJoin:
             cur = torch.cuda.current_stream(dep.device)
             if ev != cur:                      # `ev` is the depositor's stream
                 cur.wait_stream(ev)
-                if not CAPTURING:
-                    dep.record_stream(cur)
+                dep.record_stream(cur)         # also inside a capture: the depositor's stream must not reuse it under the reader
         return last, dep
 
     def deposit(self, t):
@@ -1261,7 +1260,15 @@ class SharedGrad:
     def slot(self, c0, c1):
         return _SharedSlot(self, c0, c1)
 
+    def guard(self, cur):
+        """the buffer is used on `cur`, possibly not the stream it was allocated on: the allocator must not hand its memory to a
+        later allocation of the allocating stream while `cur` still works on it.  Also inside a capture (there the block simply
+        stays reserved until the capture ends): without it a replayed step raced -- the determinism test caught it."""
+        if self.t is not None and self.stream != cur:
+            self.t.record_stream(cur)
+
     def take(self):
+        self.guard(torch.cuda.current_stream(self.device))          # the projection's backward reads it on its own stream
         t, self.t = self.t, None
         return t
 
@@ -1276,8 +1283,8 @@ class _SharedSlot:
         if o.t is None:
             o.t = torch.empty((o.M, 3 * o.d), dtype=BF16, device=o.device)
             o.stream = cur
-        elif o.stream != cur and not CAPTURING:
-            o.t.record_stream(cur)            # written on a second stream as well
+        else:
+            o.guard(cur)
         return o.t[:, self.c0:self.c1]
 
 
