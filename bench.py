@@ -170,6 +170,7 @@ def main():
     # overlap wins unless the host cannot keep the launches ahead of the GPU, the replay is immune to that.
     auto_mode = world > 1 and not a.no_graph and not a.graph_dp
     use_graph = not a.no_graph and (world == 1 or a.graph_dp)
+    exchange_mode = None
     dp = DataParallelStep(model, fusion_step_loss, overlap=not use_graph)
     from hri_emo_amd.optim import FusedClipAdamW
     opt = FusedClipAdamW(dp.buckets, lr=1e-4, weight_decay=1e-2, max_norm=5.0)     # before capture: re-homes the parameters
@@ -200,24 +201,43 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return tt.item()
         t_eager = probe()
-        ok, t_graph = 1, float("inf")
-        try:                                       # the replay mode is optional: if its capture fails on this node, stay eager
-            dp.buckets.suspended = True
-            dp.capture(*batch)
+        # two optional replay modes; a capture that fails on this node (every rank takes the same branch) just drops its mode:
+        #   "replay+captured exchange": the bucket all-reduces are part of the graph, launched where their gradients are ready
+        #                               (overlaps backward like the eager mode, without ~450 host launches per step)
+        #   "replay, exchange after":   the PR-safe form: collectives stay outside the graph and follow the replay
+        modes = {"eager": t_eager}
+
+        def try_capture(name, **kw):
+            ok = 1
+            try:
+                dp.capture(*batch, **kw)
+                dp.use_graph(True)
+            except Exception as e:                 # noqa: BLE001
+                ok = 0
+                log(f"rank {rank}: capturing the step ({name}) failed ({type(e).__name__}: {e})")
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                modes[name] = probe()
+            return int(flag.item()) == 1
+
+        # (opt-in: HRIEMO_BENCH_CAPTURED_EXCHANGE=1.  It is rehearsed on one rank over RCCL in the GPU suite, but it has never run
+        # on more than one GPU -- no multi-GPU node was available to the builder -- and a collective that hangs inside a
+        # capture would take the whole scaling run with it; the two modes below are the measured-safe defaults)
+        if os.environ.get("HRIEMO_BENCH_CAPTURED_EXCHANGE", "0") == "1":
+            try_capture("replay+captured exchange", collectives=True)
+        dp.buckets.suspended = True
+        try_capture("replay, exchange after")
+        best = min(modes, key=modes.get)
+        if best == "replay+captured exchange":
+            dp.capture(*batch, collectives=True)       # the later capture replaced it
             dp.use_graph(True)
-        except Exception as e:                     # noqa: BLE001
-            ok = 0
-            log(f"rank {rank}: capturing the step failed ({type(e).__name__}: {e}); eager mode only")
-        flag = torch.tensor([ok], device=device, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # every rank takes the same branch
-        if int(flag.item()) == 1:
-            t_graph = probe()
-        use_graph = t_graph < t_eager
+        use_graph = best != "eager"
         dp.use_graph(use_graph)
         if not use_graph:
             dp.buckets.suspended = False
-        log(f"N={world}: eager + overlapped exchange {t_eager * 1e3:.3f} ms/step, replay + exchange after {t_graph * 1e3:.3f} ms/step -> "
-            f"{'replay' if use_graph else 'eager'}")
+        exchange_mode = best
+        log(f"N={world}: " + ", ".join(f"{k} {v * 1e3:.3f} ms/step" for k, v in modes.items()) + f" -> {best}")
     for _ in range(a.warmup):
         dp.step(*batch)
     sync()
@@ -325,21 +345,23 @@ def main():
         # the same hand-over the way a trainer on this package does it (hri_emo_amd.data.DevicePrefetcher: pinned double
         # buffers, copy stream, the copy of batch k+1 beside the step on batch k): every step takes a FRESH host batch
         from hri_emo_amd.data import DevicePrefetcher
-        nst = max(a.steps, 10)
-        pf = DevicePrefetcher((host for _ in range(nst + 3)), device, depth=3)
-        it = iter(pf)
-        for _ in range(3):
-            dp.step(*next(it))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for bt in it:
-            dp.step(*bt)
-        torch.cuda.synchronize()
-        ov_ms = (time.perf_counter() - t1) / nst * 1e3
-        h2d["ms_per_step_with_prefetched_h2d"] = round(ov_ms, 3)
-        h2d["value_with_prefetched_h2d"] = round(B / (ov_ms * 1e-3), 1)
-        log(f"steps fed by the prefetcher (fresh pinned host batch per step, copy overlapped): {ov_ms:.3f} ms/step")
-        del host, pf, it
+        nst = max(a.steps, 10) if world == 1 else 0     # (rank-local leg: dp.step exchanges gradients, so one rank only)
+        if nst:
+            pf = DevicePrefetcher((host for _ in range(nst + 3)), device, depth=3)
+            it = iter(pf)
+            for _ in range(3):
+                dp.step(*next(it))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for bt in it:
+                dp.step(*bt)
+            torch.cuda.synchronize()
+            ov_ms = (time.perf_counter() - t1) / nst * 1e3
+            h2d["ms_per_step_with_prefetched_h2d"] = round(ov_ms, 3)
+            h2d["value_with_prefetched_h2d"] = round(B / (ov_ms * 1e-3), 1)
+            log(f"steps fed by the prefetcher (fresh pinned host batch per step, copy overlapped): {ov_ms:.3f} ms/step")
+            del pf, it
+        del host
 
     # north_star sub-target: the cross-attention QK^T / AV cores alone (both directions, dropout as in the step),
     # algorithmic FLOPs (fwd 4*B*H*Lq*Lk*hd, bwd 2x) over the kernels' own time, against the dense bf16 MFMA peak and
@@ -447,7 +469,7 @@ def main():
                                       f"T_t={T_T} N_e={CFG['num_emotions']} H=8, {CFG['num_layers_fusion']} fusion + {CFG['num_layers_decoder']} decoder layers, "
                                       f"all-False masks (BASELINE {a.workload})",
                           "global_batch": B * world, "batch_per_gpu": B, "parallelism": f"dp{world}",
-                          "grad_allreduce": ("fp32 flat buckets 32MiB, RCCL, " + ("after the replay" if use_graph else "launched from gradient-ready hooks during backward")) if world > 1 else "none",
+                          "grad_allreduce": ("fp32 flat buckets 32MiB, RCCL, " + (exchange_mode or ("after the replay" if use_graph else "launched from gradient-ready hooks during backward"))) if world > 1 else "none",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "streams": 2 if os.environ.get("HRIEMO_TWO_STREAMS", "1") != "0" else 1},
                "host_enqueue_ms_per_step": round(host_ms, 3), "optimizer_ms_per_step": None if opt_ms is None else round(opt_ms, 3), "cross_attention": xattn, "ragged_masks": ragged, "pcie": h2d,

@@ -1255,7 +1255,17 @@ class SharedGrad:
     reads ONE dY operand.  A slot is a column range of it; the buffer is allocated by whichever slot is asked first."""
 
     def __init__(self, M, d, device):
-        self.M, self.d, self.device, self.t = M, d, device, None
+        # Allocated HERE, in the forward, on the stream of its projection and before the branches exchange their K | V halves
+        # (a point both streams are ordered behind): never in backward by whichever attention core comes first.  A buffer born
+        # in backward on one stream can be written by the OTHER stream before the allocating stream has run the kernels that
+        # still read the block's previous occupant -- the allocator only orders reuse within the allocating stream.  That was a
+        # real race: the text branch's dQ landed in a block the audio branch's pending FFN dX GEMM still read its residual
+        # operand from (scripts_dev/soak_step.py 500 16 ragged: a handful of dirty replays in 500, first differing word always
+        # layer 1's attn_a2t.out_proj gradient).  Cost: (M_a + M_t) x 3d bf16 per layer held from forward to backward (312 MB
+        # at cfg 2).
+        self.M, self.d, self.device = M, d, device
+        self.t = torch.empty((M, 3 * d), dtype=BF16, device=device) if torch.is_grad_enabled() else None
+        self.stream = torch.cuda.current_stream(device) if self.t is not None else None
 
     def slot(self, c0, c1):
         return _SharedSlot(self, c0, c1)
@@ -1280,11 +1290,14 @@ class _SharedSlot:
     def buf(self):
         o = self.owner
         cur = torch.cuda.current_stream(o.device)
-        if o.t is None:
+        if o.t is None:                       # (forward ran under no_grad, or the buffer was already consumed: a second backward)
             o.t = torch.empty((o.M, 3 * o.d), dtype=BF16, device=o.device)
             o.stream = cur
+            o.late = True
         else:
             o.guard(cur)
+            if getattr(o, "late", False) and o.stream != cur:
+                cur.wait_stream(o.stream)     # born in backward after all: order this stream behind the allocating one first
         return o.t[:, self.c0:self.c1]
 
 

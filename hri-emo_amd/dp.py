@@ -20,8 +20,11 @@ class GradBuckets:
     bf16 and cast back into the fp32 flat buffer (the 1/N average is applied in fp32).  A bf16 sum over N <= 8 ranks adds
     ~2^-9 relative rounding per addition on top of the bf16 backward that produced the gradients."""
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True, comm_dtype=torch.float32):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True, comm_dtype=torch.float32, force_exchange=False):
+        """force_exchange: install the hooks and run the collectives at world size 1 too (a one-rank all-reduce is the identity:
+        rehearses the exchange -- also captured inside a hipGraph -- on a one-GPU box)"""
         self.params = [p for p in params if p.requires_grad]
+        self.force_exchange = bool(force_exchange) and dist.is_initialized()
         self.group = group
         self.comm_dtype = comm_dtype
         self._stage = None
@@ -59,7 +62,7 @@ class GradBuckets:
         self.suspended = False      # True: gradient-ready notifications are ignored (rank-local diagnostic steps: no collectives)
         self._works = []
         self._hooks = []
-        if overlap and self.world > 1:
+        if overlap and (self.world > 1 or self.force_exchange):
             from . import _ops
             # an overlapped exchange wants gradients in production order; one predicate per GradBuckets (a second instance --
             # an eval or EMA wrapper -- must not switch the first one's deferral of small weight-gradient GEMMs on or off)
@@ -85,22 +88,45 @@ class GradBuckets:
     def _launch(self, bi):
         s, e, _ = self.buckets[bi]
         self._launched[bi] = True
+        ctx = None
         if self.flat.is_cuda:
-            # a bucket holds gradients written on both branch streams: the collective is ordered after the launching
-            # (current) stream only, so that stream first waits for the other one
+            # a bucket holds gradients written on both branch streams: the collective is ordered after the launching stream
+            # only, so that stream first waits for the other one.  Eager steps launch from the stream the gradient-ready
+            # notification came in on.  (Round 3 also tried "always from the main stream, which first waits for the notifying
+            # one"; in the two-rank rehearsal over gloo that form sporadically sent a bucket out with a wrong half of an
+            # in-projection gradient -- scripts_dev/dbg_dp_overlap.py.  The experiment predates the fix of the SharedGrad
+            # first-touch race (_ops.SharedGrad) and may have been that fault; the form measured correct stays for eager steps.)
+            # Inside a capture the launch MUST come from the capture's origin stream: the
+            # process group forks its communication stream from the launching one, and a fork off the side stream would be a
+            # fork nested in a fork (_ops.fork; hipStreamEndCapture crashes on those).
             from . import _ops
+            streams = _ops.branch_streams(self.flat.device)
             cur = torch.cuda.current_stream(self.flat.device)
-            for st in _ops.branch_streams(self.flat.device):
-                if st != cur:
-                    cur.wait_stream(st)
-        if self.comm_dtype == torch.float32:
-            self._works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
-        else:
-            if self._stage is None:
-                self._stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
-            st = self._stage[s:e]
-            st.copy_(self.flat[s:e])                    # fp32 -> bf16 on the launching stream, ordered before the collective
-            self._works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (s, e)))
+            if _ops.CAPTURING and _ops.CAPTURE_ORIGIN is not None:
+                main = _ops.CAPTURE_ORIGIN
+                for st in streams:
+                    if st != main:
+                        main.wait_stream(st)
+                if cur != main:
+                    main.wait_stream(cur)
+                    ctx = torch.cuda.stream(main)
+                    ctx.__enter__()
+            else:
+                for st in streams:
+                    if st != cur:
+                        cur.wait_stream(st)
+        try:
+            if self.comm_dtype == torch.float32:
+                self._works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
+            else:
+                if self._stage is None:
+                    self._stage = torch.empty(self.flat.numel(), dtype=self.comm_dtype, device=self.flat.device)
+                st = self._stage[s:e]
+                st.copy_(self.flat[s:e])                    # fp32 -> bf16 on the launching stream, ordered before the collective
+                self._works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), (s, e)))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
 
     def _on_grad(self, p, from_sink=False):
         """gradient of `p` is final.  Sources: autograd's post-accumulate hook (gradients returned as tensors) and
@@ -131,7 +157,7 @@ class GradBuckets:
 
     def finish(self):
         """Complete the gradient exchange of this step and average over ranks."""
-        if self.world > 1:
+        if self.world > 1 or self.force_exchange:
             for bi in range(len(self.buckets)):
                 if not self._launched[bi]:          # no hooks, or a parameter got no gradient this step
                     self._launch(bi)
@@ -145,7 +171,8 @@ class GradBuckets:
             self._reported = set()
             for p in self.params:
                 p._hriemo_sink_managed = False
-            self.flat.mul_(1.0 / self.world)
+            if self.world > 1:
+                self.flat.mul_(1.0 / self.world)
 
     def grad_norm(self):
         return self.flat.norm()
@@ -171,12 +198,13 @@ class DataParallelStep:
 
     _capture_streams = {}         # device index -> the one stream every capture of this process records on
 
-    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True, comm_dtype=torch.float32):
+    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True, comm_dtype=torch.float32, force_exchange=False):
         self.model, self.loss_fn = model, loss_fn
         self._keep = []
+        self._exchange_in_graph = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype)
+        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype, force_exchange)
         self._graph = None
         self._static = None
         self._static_loss = None
@@ -213,11 +241,23 @@ class DataParallelStep:
         self.buckets.finish()
         return total
 
-    def capture(self, h_a, h_t, m_a, m_t, y):
-        """Record one step on static copies of the batch tensors; later ``step()`` calls replay it."""
+    def capture(self, h_a, h_t, m_a, m_t, y, collectives=False):
+        """Record one step on static copies of the batch tensors; later ``step()`` calls replay it.
+
+        collectives=True: the gradient exchange is captured INSIDE the graph -- every bucket's all-reduce is launched from its
+        gradient-ready hook while backward is being recorded (on the capture's origin stream; the process group forks its
+        communication stream from there), the waits and the 1/N average close the graph -- so a replay overlaps the exchange
+        with backward exactly like the eager mode does, without the host enqueueing ~450 launches per step.  Needs a backend
+        whose collectives can be stream-captured (RCCL can); the hooks must be installed (overlap=True) and not suspended."""
         from . import _ops
-        if self.buckets._hooks and not self.buckets.suspended:
-            raise RuntimeError("capture() needs GradBuckets(overlap=False) or buckets.suspended = True: collectives are not captured")
+        if collectives and not self.buckets._hooks:
+            raise RuntimeError("capture(collectives=True) needs the gradient-ready hooks: GradBuckets(overlap=True) at world size > 1 "
+                               "(or force_exchange=True)")
+        if not collectives and self.buckets._hooks and not self.buckets.suspended:
+            raise RuntimeError("capture() needs GradBuckets(overlap=False) or buckets.suspended = True, or collectives=True to "
+                               "capture the exchange as well")
+        if collectives:
+            self.buckets.suspended = False
         self._static = [None if t is None else t.clone() for t in (h_a, h_t, m_a, m_t, y)]
         self.release_graph()              # a re-capture replaces the old graph: its pinned buffers go first
         # ONE capture stream per device for every capture of the process: workspaces are keyed by stream, a fresh stream per
@@ -230,6 +270,8 @@ class DataParallelStep:
         with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture wants
             for _ in range(2):
                 self._fwd_bwd(*self._static)
+                if collectives:
+                    self.buckets.finish()         # the warm-up steps exchange eagerly (every rank alike) and leave the buckets reset
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -243,6 +285,8 @@ class DataParallelStep:
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 _ops.bump_seed_word(self._static[0].device)
                 self._static_loss = self._fwd_bwd(*self._static)
+                if collectives:
+                    self.buckets.finish()         # waits on the captured collectives + the average: part of the graph
         finally:
             _ops.CAPTURING = False
             _ops.CAPTURE_ORIGIN = None
@@ -255,6 +299,9 @@ class DataParallelStep:
         self._mask_seen = {}              # k -> (data_ptr, _version) of the caller's mask tensor last compared with the captured one
         self._graph = graph
         self._replay = True
+        self._exchange_in_graph = bool(collectives)
+        if collectives:
+            self.buckets.suspended = True         # from now on hooks fire only inside replays (they are baked into the graph)
 
     def release_graph(self):
         """drop the captured step (before a re-capture, or to free its buffers): the graph, the buffers its kernels point into"""
@@ -271,7 +318,7 @@ class DataParallelStep:
         """Switch between the captured replay (gradient exchange after it) and eager launches (exchange from the
         gradient-ready hooks during backward, if installed)."""
         self._replay = bool(on) and self._graph is not None
-        self.buckets.suspended = self._replay
+        self.buckets.suspended = self._replay     # eager steps: the hooks drive the exchange; replays: it follows / is inside the graph
 
     def step(self, h_a, h_t, m_a, m_t, y):
         if self._graph is not None and getattr(self, "_replay", True):
@@ -290,7 +337,8 @@ class DataParallelStep:
                         continue
                     s.copy_(t)
             self._graph.replay()
-            self.buckets.finish()
+            if not self._exchange_in_graph:
+                self.buckets.finish()
             return self._static_loss
         loss = self._fwd_bwd(h_a, h_t, m_a, m_t, y)
         self.buckets.finish()

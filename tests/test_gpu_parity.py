@@ -1035,3 +1035,46 @@ def test_device_prefetcher_overlapped_copies_hand_out_the_right_batches(H):
             assert torch.equal(keep[2].cpu(), host[i][2]) and torch.equal(keep[3].cpu(), host[i][4])
             n += 1
         assert n == 12
+
+
+def test_gradient_exchange_captured_inside_the_step_graph(H):
+    """dp.DataParallelStep.capture(collectives=True): the bucket all-reduces are launched from the gradient-ready hooks WHILE the
+    backward is being captured and replayed with the step.  One rank over RCCL (a one-rank all-reduce is the
+    identity, but the collective kernels, the process group's communication stream and its fork / join inside the capture are
+    all real): the replayed gradients must equal the eager step's bit for bit, replay after replay, several buckets."""
+    import torch.distributed as dist
+    from hri_emo_amd import _ops
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    import socket
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(21)
+        m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=5, n_heads=8, dropout=0.0).cuda().train()
+        h_a, h_t, m_a, m_t = _rand_batch(6, 90, 36, 256, 41)
+        y = (torch.rand(6, 5, generator=torch.Generator().manual_seed(5)) < 0.3).float().cuda()
+        batch = (cu(h_a).bfloat16(), cu(h_t).bfloat16(), cu(m_a), cu(m_t), y)
+        dp = DataParallelStep(m, fusion_step_loss, bucket_bytes=512 << 10, overlap=True, force_exchange=True)
+        assert len(dp.buckets.buckets) > 3 and dp.buckets._hooks
+        dp.step(*batch)                                   # eager: hooks launch the collectives during backward
+        torch.cuda.synchronize()
+        ref = dp.buckets.flat.clone()
+        assert float(ref.norm()) > 0
+        dp.capture(*batch, collectives=True)
+        for _ in range(3):
+            loss = dp.step(*batch)
+            torch.cuda.synchronize()
+            assert torch.equal(dp.buckets.flat, ref)
+        dp.use_graph(False)                               # and back to eager launches with the hook-driven exchange
+        dp.step(*batch)
+        torch.cuda.synchronize()
+        assert torch.equal(dp.buckets.flat, ref)
+        dp.buckets.close()
+    finally:
+        dist.destroy_process_group()
