@@ -219,6 +219,42 @@ class Shadows:
         for p in params:
             self.get(p)
 
+    def plan(self, p, jobs):
+        """get() without the launch: if the shadow of `p` is stale, its cast is appended to `jobs` (cast_batch() issues them all
+        in one launch) and the entry is marked fresh for this step"""
+        key = id(p)
+        ent = self._d.get(key)
+        ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
+        if (CAPTURING and (ent is None or len(ent) < 3 or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != p.device:
+            s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
+                torch.empty(p.shape, dtype=BF16, device=p.device)
+            _require_gpu(p)
+            _require_fp32_master(p)
+            if not p.is_contiguous():
+                return self.get(p)
+            jobs.append((p.data_ptr(), s.data_ptr(), p.numel()))
+            self._d[key] = (ver, s, STEP_ID)
+
+    def plan_cat(self, parts, jobs):
+        """get_cat() without the launches (one job per part)"""
+        key = ("cat",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
+        ent = self._d.get(key)
+        ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
+        dev = parts[0][0].device
+        if (CAPTURING and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != dev:
+            if not all(p.is_contiguous() for p, _, _ in parts):
+                return self.get_cat(parts)
+            rows = sum(r1 - r0 for _, r0, r1 in parts)
+            K = parts[0][0].shape[1]
+            s = ent[1] if ent is not None and ent[1].device == dev else torch.empty((rows, K), dtype=BF16, device=dev)
+            at = 0
+            for p, r0, r1 in parts:
+                _require_gpu(p)
+                _require_fp32_master(p)
+                jobs.append((p.data_ptr() + r0 * K * 4, s.data_ptr() + at * K * 2, (r1 - r0) * K))
+                at += r1 - r0
+            self._d[key] = (ver, s, STEP_ID)
+
     def get_cat(self, parts):
         """bf16 shadow of the row-wise concatenation of master slices: parts = ((param, r0, r1), ...) -> [sum(r1 - r0), K].
         One GEMM per shared input (SharedProjFn) reads it; refreshed when any of the masters changes, like get()."""
@@ -256,6 +292,13 @@ class Shadows:
             ent = (ver, v, STEP_ID)
             self._d[key] = ent
         return ent[1]
+
+
+def cast_batch(jobs):
+    """issue the planned fp32 -> bf16 casts (Shadows.plan / plan_cat) as one launch on the current stream"""
+    if jobs:
+        host = torch.tensor(jobs, dtype=torch.int64)
+        _lib.call("hriemo_cast_f32_to_bf16_batch", host.data_ptr(), len(jobs), _stream())
 
 
 FUSED_WGRAD = True

@@ -16,6 +16,10 @@ except ImportError:            # imported as top-level `models` (PYTHONPATH=<rep
     from hri_emo_amd import _ops
 
 
+import os as _os
+_AUDIO_FIRST = _os.environ.get("HRIEMO_AUDIO_FIRST", "1") != "0"
+
+
 class CrossModalBlock(nn.Module):
     def __init__(self, d_model=768, n_heads=8, dropout=0.1):
         super().__init__()
@@ -63,6 +67,23 @@ class CrossModalBlock(nn.Module):
     def _ffn(self, x, x32, ffn, ln, p, seed, site, seq=None):
         return _ops.FFNLN.apply(x, x32, ffn[0].weight, ffn[0].bias, ffn[2].weight, ffn[2].bias, ln.weight, ln.bias,
                                 self._sh, p, 0.0, seed, site, self.batch_offset, seq)
+
+    def _plan_shadows(self, jobs):
+        """bf16 shadows this block's forward will ask for, as cast jobs for ONE batched launch (_ops.cast_batch)"""
+        sh, d = self._sh, self.d_model
+        a2t, t2a = self.attn_a2t, self.attn_t2a
+        for mha in (self.self_attn_a, self.self_attn_t):
+            sh.plan(mha.in_proj_weight, jobs)
+            sh.plan(mha.out_proj.weight, jobs)
+        if _ops.shared_proj() and _ops.gemm_mode() == "bf16":
+            sh.plan_cat(((a2t.in_proj_weight, 0, d), (t2a.in_proj_weight, d, 3 * d)), jobs)
+            sh.plan_cat(((t2a.in_proj_weight, 0, d), (a2t.in_proj_weight, d, 3 * d)), jobs)
+        else:
+            sh.plan(a2t.in_proj_weight, jobs)
+            sh.plan(t2a.in_proj_weight, jobs)
+        for w in (a2t.out_proj.weight, t2a.out_proj.weight, self.ffn_a[0].weight, self.ffn_a[2].weight, self.ffn_t[0].weight,
+                  self.ffn_t[2].weight):
+            sh.plan(w, jobs)
 
     def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, plan=None):
         """(bf16, fp32-twin) pairs in and out; returns (a, a32, t, t32, maps|None).
@@ -113,27 +134,43 @@ class CrossModalBlock(nn.Module):
         elif shared:
             # two streams, one GEMM per shared input: each branch projects its own self-attention output to [Q | K, V] on its own
             # stream (no dependence on the other branch yet), THEN the branches exchange the K | V halves and run the cores
+            # (the audio branch -- three times the rows, the critical path -- is ENQUEUED first at every fork: the order of capture
+            # decides which branch the graph runtime starts first, HRIEMO_AUDIO_FIRST=0 restores text first)
             _ops.fork(side, main)
             for x_ in (t, t32, kpm_t, kpm_a):
                 _ops.share(x_, side)
-            with torch.cuda.stream(side):
-                t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
-                jt = join_for(t_s)
-                q_t2a, kv_a2t, sgt = self._shared_proj(t_s, self.attn_t2a, self.attn_a2t, jt)
+
+            def text_self():
+                with torch.cuda.stream(side):
+                    t_s_, t_s32_, w_t_ = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
+                    jt_ = join_for(t_s_)
+                    return (t_s_, t_s32_, w_t_, jt_) + self._shared_proj(t_s_, self.attn_t2a, self.attn_a2t, jt_)
+
+            if not _AUDIO_FIRST:
+                t_s, t_s32, w_t, jt, q_t2a, kv_a2t, sgt = text_self()
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
             ja = join_for(a_s)
             q_a2t, kv_t2a, sga = self._shared_proj(a_s, self.attn_a2t, self.attn_t2a, ja)
+            if _AUDIO_FIRST:
+                t_s, t_s32, w_t, jt, q_t2a, kv_a2t, sgt = text_self()
             main.wait_stream(side)
             _ops.fork(side, main)
             _ops.share(kv_a2t, main)
             _ops.share(kv_t2a, side)
-            with torch.cuda.stream(side):
-                x, x32, w_t2a = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
-                                            kv_t2a, jt, q_t2a, (sgt.slot(0, d), sga.slot(d, 3 * d)))
-                t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None)
+
+            def text_cross():
+                with torch.cuda.stream(side):
+                    x_, x32_, w_ = self._cross(t_s, t_s32, a_s, self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
+                                               kv_t2a, jt, q_t2a, (sgt.slot(0, d), sga.slot(d, 3 * d)))
+                    return self._ffn(x_, x32_, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None) + (w_,)
+
+            if not _AUDIO_FIRST:
+                t_cm, t_cm32, w_t2a = text_cross()
             x, x32, w_a2t = self._cross(a_s, a_s32, t_s, self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
                                         kv_a2t, ja, q_a2t, (sga.slot(0, d), sgt.slot(d, 3 * d)))
             a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)
+            if _AUDIO_FIRST:
+                t_cm, t_cm32, w_t2a = text_cross()
             main.wait_stream(side)
             for x_ in (t_cm, t_cm32, w_t, w_t2a):
                 _ops.share(x_, main)

@@ -13,6 +13,12 @@ from .emotion_decoder import EmotionDecoder
 
 import os as _os
 _PREFETCH = _os.environ.get("HRIEMO_PREFETCH_SHADOWS", "1") != "0"
+# all weight shadows of a step from two batched cast launches (hriemo_cast_f32_to_bf16_batch) instead of one ~5 us launch per
+# matrix.  Built in round 3 because the step's first GEMM starts 220 us into the replay behind a chain of 16 small casts
+# (profiles/r03_step_timeline.txt) -- and measured SLOWER on one box (8.19-8.23 vs 8.14 ms per step, scripts_dev/replay_only.py):
+# the graph runtime starts the audio branch late either way, and two bandwidth-heavy bursts at the top cost more than the small
+# casts that hide in gaps later.  Opt-in.
+_BATCHED_CASTS = _os.environ.get("HRIEMO_BATCHED_CASTS", "0") == "1"
 
 
 class FusionWithEmotionDecoder(nn.Module):
@@ -33,25 +39,55 @@ class FusionWithEmotionDecoder(nn.Module):
                 m.batch_offset = int(offset)
 
     def _prefetch_shadows(self, device):
-        """bf16 copies of the gate's and the decoder's weights, cast on the side stream at the top of the step: on the decoder's
-        serial chain of latency-bound launches the 18 cast kernels were 90 us per step that nothing could hide (the encoder's
-        casts hide under its GEMMs).  Returns the event the consumer stream waits for, or None (one stream / fp32 mode)."""
+        """bf16 copies of EVERY weight matrix of the step from two batched cast launches at the top of the step: the first
+        fusion layer's on the caller's stream (its GEMMs come first), everything else -- further layers, gate, decoder -- on the
+        side stream beside them.  Before: one ~5 us cast launch per matrix, 16 of them a serial chain on the side stream that
+        the step's first GEMM ended up behind (profiles/r03_step_timeline.txt: 220 us into the step), and the decoder's on its
+        latency-bound chain.  Returns the event the consumer stream waits for, or None (one stream / fp32 / fp8 mode)."""
         if _ops.precision() != "bf16" or not device.type == "cuda" or not _PREFETCH:
             return None
+        layers = list(self.cross_modal.layers)
+        batched = _ops.gemm_mode() == "bf16" and _BATCHED_CASTS
+        if batched and layers:
+            jobs = []
+            layers[0]._plan_shadows(jobs)
+            _ops.cast_batch(jobs)
         side = _ops.side_stream(device)
         if side is None:
+            if batched:
+                jobs = []
+                for blk in layers[1:]:
+                    blk._plan_shadows(jobs)
+                self._plan_tail_shadows(jobs)
+                _ops.cast_batch(jobs)
             return None
         main = torch.cuda.current_stream(device)
         _ops.fork(side, main)                       # the masters may have just been updated on the caller's stream
         with torch.cuda.stream(side):
-            g = self.beta_gate
-            g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))
-            for layer in self.emotion_decoder.layers:
-                layer._sh.prefetch((layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
-                                    layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight))
+            if batched:
+                jobs = []
+                for blk in layers[1:]:
+                    blk._plan_shadows(jobs)
+                self._plan_tail_shadows(jobs)
+                _ops.cast_batch(jobs)
+            else:
+                g = self.beta_gate
+                g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))
+                for layer in self.emotion_decoder.layers:
+                    layer._sh.prefetch((layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
+                                        layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight))
             ev = torch.cuda.Event()
             ev.record(side)
         return ev
+
+    def _plan_tail_shadows(self, jobs):
+        g = self.beta_gate
+        g._sh.plan(g.mlp[0].weight, jobs)
+        g._sh.plan(g.mlp[2].weight, jobs)
+        for layer in self.emotion_decoder.layers:
+            for w in (layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
+                      layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight):
+                layer._sh.plan(w, jobs)
 
     def _ensure_3d(self, x):
         if x.dim() == 2:

@@ -174,6 +174,9 @@ int hriemo_colsum_bf16(const void* X, long ldx, int M, int N, float* out, int ac
                        hriemo_stream_t stream);                                   /* bias gradients */
 int hriemo_cast_f32_to_bf16(const float* src, void* dst, long n, hriemo_stream_t stream);   /* bf16 shadows */
 int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hriemo_stream_t stream);
+/* njobs casts in one launch (64 per launch): jobs_host = HOST array of njobs x 3 int64 {src fp32, dst bf16, n elements}, 16-byte
+ * aligned pointers; the table is passed through kernel arguments (capture-safe).  The bf16 shadows of all weights of a step. */
+int hriemo_cast_f32_to_bf16_batch(const void* jobs_host, int njobs, hriemo_stream_t stream);
 int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed,
                         const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
 int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
