@@ -390,7 +390,7 @@ def main():
             q = torch.randn(B * Lq, CFG["d_model"], device=device).bfloat16()
             k = torch.randn(B * Lk, CFG["d_model"], device=device).bfloat16()
             v = torch.randn(B * Lk, CFG["d_model"], device=device).bfloat16()
-            wb = _ops.attn_mask_bits(B, Hh, Lk, hd)    # what the step itself does: bit words where the backward is one kernel
+            wb = _ops.attn_mask_bits(B, Hh, Lk, hd, Lq)    # what the step itself does: bit words where the backward is one kernel
             o, lse, mbits = _ops.attn_fwd(q, k, v, B, Hh, Lq, Lk, hd, None, pd, 1234, 5, 0, want_bits=True)
             if not wb:
                 mbits = None

@@ -27,6 +27,8 @@ _SIGS = {
     "hriemo_attn_bwd_varlen": ("plplplplplplplplppppiiiiifQpIipppp", "i"),
     "hriemo_attn_mask_bytes": ("iiii", "l"),
     "hriemo_attn_bwd_single_pass": ("iiii", "i"),
+    "hriemo_attn_bwd_single_pass_q": ("iiiii", "i"),
+    "hriemo_attn_bwd_kv_colsum_rows": ("iiiii", "i"),
     "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),
     "hriemo_attn_bwd_dq_colsum_rows": ("iiiii", "i"),
     "hriemo_split_bf16x3": ("pliipiip", "i"),

@@ -630,13 +630,15 @@ def _in_backward():
 ATTN_MASK_BITS = None
 
 
-def attn_mask_bits(B, H, Lk, hd):
+def attn_mask_bits(B, H, Lk, hd, Lq=None):
     global ATTN_MASK_BITS
     if ATTN_MASK_BITS is None:
         import os
         ATTN_MASK_BITS = os.environ.get("HRIEMO_ATTN_MASK_BITS", "auto")
     if ATTN_MASK_BITS in ("0", "1"):
         return ATTN_MASK_BITS == "1"
+    if Lq is not None:
+        return bool(_lib.lib().hriemo_attn_bwd_single_pass_q(B, H, Lq, Lk, hd))
     return bool(_lib.lib().hriemo_attn_bwd_single_pass(B, H, Lk, hd))
 
 
@@ -670,7 +672,7 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
     fold = bias_grad is not None and FOLD_ATTN_BIAS
     if fold:
         L_ = _lib.lib()
-        rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
+        rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_kv_colsum_rows(B, H, Lq, Lk, hd)
         pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
         pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
     if cu is not None:
@@ -1042,7 +1044,7 @@ class SelfAttnLN(torch.autograd.Function):
         w_in16, w_out16 = sh.get(w_in), sh.get(w_out)
         qkv = proj_fwd(Operand(x2, mx_of(x)), sh, w_in, w_in16, b_in)
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-        o, lse, mbits = attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, AL, hd) else \
+        o, lse, mbits = attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, AL, hd, AL) else \
             attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
@@ -1128,7 +1130,7 @@ class CrossAttnLN(torch.autograd.Function):
             xkv2 = _contig_bf16(xkv).view(B * Lk, d)
             kv = proj_fwd(Operand(xkv2, mx_of(xkv)), sh, w_in, w_in16, b_in, rows=(d, 3 * d))
         k, v = kv[:, :d], kv[:, d:]
-        o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd) else \
+        o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd, ALq) else \
             attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
         g = proj_fwd(o, sh, w_out, w_out16, b_out)
         y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,

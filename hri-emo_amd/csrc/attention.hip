@@ -582,6 +582,246 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnArgs a0)
   }
 }
 
+// ------------------------------------------------------------------------------------------ dQ, dK, dV: query-resident single pass
+// The mirror of the key-resident single-pass kernel further down, for L_q <= 128 < L_k (text queries over audio keys, t2a at
+// cfg 2: L_q = 128, L_k = 400; the MOSEI shape's 50 x 1000): ONE 512-thread block holds ALL queries of a (batch, head) -- each of
+// its 8 waves 16 of them, on the lanes (S^T = K.Q^T as in the dQ kernel above) -- and sweeps the keys in 64-row tiles:
+//   S^T, dP^T          24 MFMAs per wave and tile; softmax / dropout arithmetic of the dQ kernel
+//   dQ^T += K^T.dS^T   12 MFMAs, dS^T straight from the accumulators as the B operand; dQ stays in registers over the sweep
+//   P~ and dS cross LDS once ([query][key] bf16 images, 8-byte stores) and every wave multiplies one 16-key slice of
+//   dV^T = dO^T.P~ (even waves) or dK^T = Q^T.dS (odd waves) over all 128 queries (24 MFMAs): these tiles are COMPLETE -- the block
+//   holds every query -- and are stored at once; Q and dO stay resident as LDS images for those products.
+// 5 GEMMs per tile instead of the two-kernel path's 7, Q / K / V / dO read once, no delta round trip, no atomics, deterministic.
+// Two barriers per tile: (C) P~ / dS images complete + K / V tile no longer read, (B) next K / V tile committed + images free.
+template <int HD, bool BITS>
+__global__ __launch_bounds__(512) void attn_bwd_qres_kernel(const AttnArgs a0) {
+  using G = AttnGeom<HD>;
+  constexpr int KS = G::KS, DT = G::DT, STRIDE = G::STRIDE, NW = 8, NT = 512, NQ = 128, KT = 64;
+  constexpr int PS = KT * 2 + 32;                    // row stride of the P~ / dS images ([query][64 keys] bf16 + pad)
+  __shared__ __attribute__((aligned(16))) char lds[2 * NQ * STRIDE + 2 * KT * STRIDE + 2 * NQ * PS + KT * 4];
+  char* const Qi = lds;
+  char* const dOi = Qi + NQ * STRIDE;
+  char* const Kt = dOi + NQ * STRIDE;
+  char* const Vt = Kt + KT * STRIDE;
+  char* const Pi = Vt + KT * STRIDE;
+  char* const dSi = Pi + NQ * PS;
+  float* const mb = (float*)(dSi + NQ * PS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, i = lane & 15;
+  const int bh = blockIdx.x;
+  const int b = bh / a0.H, h = bh - b * a0.H;
+  const AttnArgs a = localize(a0, b, h);
+  const bf16_t* Qb = a.Q + (long)b * a.Lq * a.ldq + h * HD;
+  const bf16_t* dOb = a.dO + (long)b * a.Lq * a.lddo + h * HD;
+  const bf16_t* Kb = a.K + (long)b * a.Lk * a.ldk + h * HD;
+  const bf16_t* Vb = a.V + (long)b * a.Lk * a.ldv + h * HD;
+  const int nkt = (a.Lk + KT - 1) / KT;
+  TileRegs<HD, KT, NT> kr, vr;
+  tile_fetch<HD, KT, NT>(kr, Kb, a.ldk, 0, a.Lk, tid);
+  tile_fetch<HD, KT, NT>(vr, Vb, a.ldv, 0, a.Lk, tid);
+  load_tile<HD, NQ, NT>(Qi, Qb, a.ldq, 0, a.Lq, tid);           // rows >= L_q zero
+  load_tile<HD, NQ, NT>(dOi, dOb, a.lddo, 0, a.Lq, tid);
+
+  // this lane's query (wave * 16 + i): delta = rowsum(dO * O) over the head dim (lane groups g share the work), lse
+  const int q = wave * 16 + i;
+  const bool qok = q < a.Lq;
+  const int qc = min(q, a.Lq - 1);
+  float part = 0.f;
+  {
+    const bf16_t* dop = dOb + (long)qc * a.lddo;
+    const bf16_t* op = a.O + ((long)b * a.Lq + qc) * a.ldo + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int e = ks * 32 + 8 * g;
+      if (e < HD) {
+        const bf16x8 dv8 = *(const bf16x8*)(dop + e), ov = *(const bf16x8*)(op + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)dv8[j] * (float)ov[j];
+      }
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+  }
+  const long li = ((long)b * a.H + h) * a.Lq + qc;
+  // rows past L_q: exponent constant -inf -> P~ = dS = 0, they add nothing to dK / dV
+  const float cexp = qok ? (a.thr16 != 0 ? log2f(a.inv_keep) : 0.f) - a.lse[li] * LOG2E : -INFINITY;
+  const float dlk = a.thr16 != 0 ? part / a.inv_keep : part;
+  const float sl2 = a.scale * LOG2E;
+  const uint32_t key32 = site_key(eff_seed(a.seed, a.seed_dev), a.site, (uint32_t)((a.b_offset + b) * a.H + h));
+
+  tile_commit<HD, KT, NT>(kr, Kt, tid);
+  tile_commit<HD, KT, NT>(vr, Vt, tid);
+  if (tid < KT) {
+    const bool pad = tid >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + tid] != 0);
+    mb[tid] = pad ? -INFINITY : 0.f;
+  }
+  __syncthreads();
+  bf16x8 qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = row_frag(Qi, STRIDE, q, ks * 4 + g);
+    dof[ks] = row_frag(dOi, STRIDE, q, ks * 4 + g);
+  }
+  f32x4 dq[DT], cs[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; cs[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  const int which = wave & 1, nsub = wave >> 1;       // dV (even waves) / dK (odd waves) of key sub-tile nsub of every tile
+  const char* const Yimg = which ? dSi : Pi;
+  const char* const Ximg = which ? Qi : dOi;
+  bf16_t* const dOut = which ? a.dK : a.dV;
+  const long ldout = which ? a.lddk : a.lddv;
+  const float oscale = which ? a.scale : 1.f;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) {
+      tile_fetch<HD, KT, NT>(kr, Kb, a.ldk, (kt + 1) * KT, a.Lk, tid);
+      tile_fetch<HD, KT, NT>(vr, Vb, a.ldv, (kt + 1) * KT, a.Lk, tid);
+    }
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { s[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[n] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = row_frag(Kt, STRIDE, n * 16 + i, ks * 4 + g);
+        const bf16x8 vf = row_frag(Vt, STRIDE, n * 16 + i, ks * 4 + g);
+        s[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[n], 0, 0, 0);
+        dp[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], dp[n], 0, 0, 0);
+      }
+    {
+      const uint32_t hb = drop_base(key32, (uint32_t)q, (uint32_t)((kt * KT + 4 * g) >> 1));
+      uint32_t bits = 0xffffu;
+      if (BITS && a.thr16 != 0) bits = ((const unsigned short*)(a.mbits + (((long)bh * a.Lq + qc) * nkt + kt)))[g];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const f32x4 bias = *(LDS_PTR(const f32x4))(mb + n * 16 + 4 * g);
+        bf16x4 pw, dw;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          uint32_t x = 0xffffffffu;
+          if (a.thr16 != 0 && !BITS) x = mix24(hb + (uint32_t)(n * 8 + pr) * DROP_CB);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int r = 2 * pr + e;
+            const float pk = EXP2(fmaf(s[n][r], sl2, bias[r] + cexp));
+            float dpd = dp[n][r], pd = pk;
+            if (a.thr16 != 0) {
+              const bool keep = BITS ? ((bits >> (n * 4 + r)) & 1u) != 0u : (e ? keep_hi(x, a.thr16) : keep_lo(x, a.thr16));
+              dpd = keep ? dpd : 0.f;
+              pd = keep ? pk : 0.f;
+            }
+            const float dsv = pk * (dpd - dlk);
+            s[n][r] = dsv;
+            pw[r] = (bf16_t)pd;
+            dw[r] = (bf16_t)dsv;
+          }
+        }
+        // P~[query][keys 16n + 4g .. +3] and dS likewise: one 8-byte store each
+        *(LDS_PTR(bf16x4))(Pi + q * PS + (n * 16 + 4 * g) * 2) = pw;
+        *(LDS_PTR(bf16x4))(dSi + q * PS + (n * 16 + 4 * g) * 2) = dw;
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 dsf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsf[j] = (bf16_t)s[2 * s2 + (j >> 2)][j & 3];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bf16x8 ktf = tr_frag(Kt, STRIDE, 32 * s2, dt * 16, lane);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();          // (C) every wave's P~ / dS rows are in LDS; nobody reads this K / V tile or its mask any more
+    if (kt + 1 < nkt) {
+      tile_commit<HD, KT, NT>(kr, Kt, tid);
+      tile_commit<HD, KT, NT>(vr, Vt, tid);
+      if (tid < KT) {
+        const int key = (kt + 1) * KT + tid;
+        const bool pad = key >= a.Lk || (a.kpm != nullptr && a.kpm[(long)b * a.Lk + key] != 0);
+        mb[tid] = pad ? -INFINITY : 0.f;
+      }
+    }
+    {
+      // out^T[head dim][16 keys] = X^T . Y over all 128 queries: X = dO (dV) or Q (dK), Y = P~ or dS, both read transposed
+      // in tr_frag's permuted k-order
+      f32x4 acc[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < NQ / 32; ++kk) {
+        const bf16x8 yf = tr_frag(Yimg, PS, 32 * kk, nsub * 16, lane);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x8 xf = tr_frag(Ximg, STRIDE, 32 * kk, dt * 16, lane);
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf, yf, acc[dt], 0, 0, 0);
+        }
+      }
+      const int key = kt * KT + nsub * 16 + i;
+      if (key < a.Lk) {
+        bf16_t* op = dOut + ((long)b * a.Lk + key) * ldout + h * HD + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          bf16x4 w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[dt][r] * oscale;
+            w[r] = (bf16_t)v;
+            cs[dt][r] += v;
+          }
+          *(bf16x4*)(op + dt * 16) = w;
+        }
+      }
+    }
+    __syncthreads();          // (B) next K / V tile and mask are in place; the P~ / dS images may be overwritten
+  }
+  // dQ rows of this wave + column sums (in-projection bias gradients): dQ per block, dK | dV per block (the block holds all keys)
+  f32x4 csq[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) csq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (qok) {
+    bf16_t* dqp = a.dQ + ((long)b * a.Lq + q) * a.lddq + h * HD + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      bf16x4 w;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = dq[dt][r] * a.scale;
+        w[r] = (bf16_t)v;
+        csq[dt][r] += v;
+      }
+      *(bf16x4*)(dqp + dt * 16) = w;
+    }
+  }
+  float* red = (float*)lds;                     // [NW][DT * 16] floats: the images are dead behind the loop's last barrier
+  if (a.csq != nullptr) {
+    block_colsum_store<DT, NW>(csq, red, a.csq + (long)b * ((long)a.H * HD) + h * HD, tid);
+    __syncthreads();
+  }
+  if (a.cskv != nullptr) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      f32x4 v = cs[dt];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], m, 64);
+      }
+      if (i == 0) *(f32x4*)(red + wave * (DT * 16) + dt * 16 + 4 * g) = v;
+    }
+    __syncthreads();
+    float* row = a.cskv + (long)b * (2L * a.H * HD) + h * HD;
+    for (int c = tid; c < 2 * DT * 16; c += NT) {
+      const int wh = c / (DT * 16), e = c - wh * (DT * 16);          // wh 0: dK sums (odd waves), 1: dV sums (even waves)
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += red[(2 * w + (wh == 0 ? 1 : 0)) * (DT * 16) + e];
+      row[(long)wh * a.H * HD + e] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ dK, dV (two-kernel path, hash mask)
 // The round-1 kernel, kept as it was tuned: the default backward (hash replay, dQ from its own kernel).  The kernel after it adds
 // the bit-word mask and the fused dQ; its different tile pipeline costs this one's register budget (3 blocks per CU at head_dim 96).
@@ -1356,7 +1596,25 @@ static bool bwd_fused(int Lk, int head_dim, int B, int H) {
   return on && Lk > 16 && Lk <= 128 && head_dim >= 32;
 }
 
+extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim);
 extern "C" int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim) { return bwd_fused(Lk, head_dim, B, H) ? 1 : 0; }
+
+// Query-resident single pass (attn_bwd_qres_kernel): all queries of a (batch, head) in one block, the keys swept -- for
+// 16 < L_q <= 128 < L_k (t2a at cfg 2; the key-resident form above takes L_k <= 128).  HRIEMO_ATTN_QRES_BWD=0: two kernels.
+static bool bwd_qres(int Lq, int Lk, int head_dim, int B, int H) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_QRES_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && !bwd_fused(Lk, head_dim, B, H) && Lq > 16 && Lq <= 128 && head_dim >= 32;
+}
+// 1 if the backward of this shape is ONE kernel of either form (the forward then writes the dropout keep-mask as bit words)
+extern "C" int hriemo_attn_bwd_single_pass_q(int B, int H, int Lq, int Lk, int head_dim) {
+  return (bwd_fused(Lk, head_dim, B, H) || bwd_qres(Lq, Lk, head_dim, B, H)) ? 1 : 0;
+}
+// rows of the dK | dV column-sum partials when both lengths are known (the query-resident kernel leaves one row per batch)
+extern "C" int hriemo_attn_bwd_kv_colsum_rows(int B, int H, int Lq, int Lk, int head_dim) {
+  if (bwd_qres(Lq, Lk, head_dim, B, H)) return B;
+  return hriemo_attn_bwd_colsum_rows(B, H, Lk, head_dim);
+}
 
 // rows of the column-sum partials hriemo_attn_bwd leaves behind: dK|dV side (sequence of length Lk) ...
 extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {
@@ -1367,7 +1625,7 @@ extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim) {
 }
 // ... and dQ side (depends on both lengths: the fused kernel writes one row per (batch, head))
 extern "C" int hriemo_attn_bwd_dq_colsum_rows(int B, int H, int Lq, int Lk, int head_dim) {
-  if (bwd_fused(Lk, head_dim, B, H)) return B;
+  if (bwd_fused(Lk, head_dim, B, H) || bwd_qres(Lq, Lk, head_dim, B, H)) return B;
   if (bwd_wide(Lq, B * H, head_dim)) return B * ((Lq + 127) / 128);
   if (Lq > 16) return B * ((Lq + 63) / 64);
   return B;
@@ -1449,6 +1707,21 @@ static int attn_bwd_impl(const void* Q, long ldq, const void* K, long ldk, const
     }
 #undef CALLF
     HRIEMO_LAUNCH_CHECK("attn_bwd_dkv_kernel (fused dQ)");
+    hriemo_prof_end(HP_ATTN_BWD_DKV, st, 10.0 * B * H * (double)Lq * Lk * head_dim);
+    return 0;
+  }
+  if (bwd_qres(Lq, Lk, head_dim, B, H)) {
+    hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
+    if (bits) {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_qres_kernel<HD, true>), dim3(B * H), dim3(512), 0, st, a)
+      DISPATCH_HD_EVEN(head_dim, CALL)
+#undef CALL
+    } else {
+#define CALL(HD) hipLaunchKernelGGL((attn_bwd_qres_kernel<HD, false>), dim3(B * H), dim3(512), 0, st, a)
+      DISPATCH_HD_EVEN(head_dim, CALL)
+#undef CALL
+    }
+    HRIEMO_LAUNCH_CHECK("attn_bwd_qres_kernel");
     hriemo_prof_end(HP_ATTN_BWD_DKV, st, 10.0 * B * H * (double)Lq * Lk * head_dim);
     return 0;
   }

@@ -102,6 +102,11 @@ long hriemo_attn_mask_bytes(int B, int H, int Lq, int Lk);
 /* 1 when hriemo_attn_bwd runs as the single kernel for this problem (the bit words pay there; the two-kernel path is as fast
  * replaying the hash) -- what the host side asks before it requests drop_mask_bits from the forward */
 int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim);
+/* Both lengths known: 1 if the backward of this shape is ONE kernel -- the key-resident form above (16 < L_k <= 128) or the
+ * query-resident one (16 < L_q <= 128 < L_k: all queries of a (batch, head) in one block, dQ in registers, complete dK / dV tiles
+ * per key tile) -- and the rows of the dK | dV column-sum partials hriemo_attn_bwd then leaves behind. */
+int hriemo_attn_bwd_single_pass_q(int B, int H, int Lq, int Lk, int head_dim);
+int hriemo_attn_bwd_kv_colsum_rows(int B, int H, int Lq, int Lk, int head_dim);
 /* Packed (varlen) sequences, SURVEY 8(f) rank 4: the reference pads every sample to the batch maximum
  * (scripts/fusion/train_fusion_seq_level_decoder.py:191-232) and computes the PAD rows; here Q / O / dO / dQ hold the valid rows of
  * all samples back to back (sample b = rows cu_seqlens_q[b] .. cu_seqlens_q[b+1]-1) and K / V / dK / dV likewise with

@@ -213,6 +213,10 @@ ATTN_CASES = [  # B, H, Lq, Lk, hd, masked, p
     (3, 4, 70, 40, 64, True, 0.1),        # L_k <= 64: one 16-key sub-tile per wave
     (2, 2, 33, 17, 32, False, 0.2),
     (2, 8, 400, 129, 96, True, 0.1),      # one key past the single-pass limit: two-kernel path with the bit-word mask
+    (2, 8, 128, 400, 96, True, 0.1),      # query-resident single pass (L_q <= 128 < L_k): t2a at cfg 2, ragged keys, dropout
+    (3, 4, 100, 300, 128, True, 0.1),     # ... head_dim 128, query tail (100 of 128 rows), key tail (300 = 4 tiles + 44)
+    (2, 4, 17, 129, 64, False, 0.2),      # ... smallest shape that takes it
+    (32, 8, 128, 400, 96, False, 0.1),    # ... every CU busy (256 blocks)
 ]
 
 
@@ -281,7 +285,7 @@ def test_attention_fwd_bwd(ops, B, H, Lq, Lk, hd, masked, p):
     # by-product: per-block column sums of dQ and dK|dV (in-projection bias gradient) through the C-ABI
     from hri_emo_amd import _lib
     L_ = _lib.lib()
-    rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_colsum_rows(B, H, Lk, hd)
+    rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_kv_colsum_rows(B, H, Lq, Lk, hd)
     pq = torch.full((rq, d), float("nan"), device="cuda")
     pkv = torch.full((rk, 2 * d), float("nan"), device="cuda")
     dq2, dkv2 = torch.empty_like(qd), torch.empty_like(kvd)
