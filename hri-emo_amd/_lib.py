@@ -15,6 +15,7 @@ _SIGS = {
     "hriemo_gemm_bf16": ("iiiiiplplplipipliplp", "i"),
     "hriemo_gemm_force_config": ("i", "i"),
     "hriemo_gemm_colsum_rows": ("iiiii", "i"),
+    "hriemo_gemm_bf16_group_tn": ("piip", "i"),
     "hriemo_gemm_bf16_split": ("iiiiiplplplpliiplp", "i"),
     "hriemo_gemm_bf16_colsum": ("iiiiiplplplplpp", "i"),
     "hriemo_mx8_scale_ld": ("i", "l"),

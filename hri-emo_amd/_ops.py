@@ -834,6 +834,7 @@ _deferred = _DeferredReduce()
 # HRIEMO_DEFER_SMALL_DW=0 disables it.
 GATE_TWO_STREAMS = _os.environ.get("HRIEMO_GATE_TWO_STREAMS", "1") != "0"     # the gate's text-side LayerNorm + pooling on the side stream
 DEFER_SMALL_DW = _os.environ.get("HRIEMO_DEFER_SMALL_DW", "1") != "0"
+GROUP_SMALL_DW = _os.environ.get("HRIEMO_GROUP_SMALL_DW", "1") != "0"      # the queued weight gradients leave as one grouped GEMM launch
 SMALL_DW_ROWS = 1024
 FLUSH_SITES = set()                # dropout-site ids of the sub-layers whose backward ends a model's text branch (one per CrossModalTransformer)
 _hook_predicates = []              # one per live dp.GradBuckets with gradient-ready hooks (register_hook_predicate)
@@ -881,9 +882,17 @@ class _DeferredWgrad:
         jobs, self.jobs = self.jobs, []
         if jobs:
             cur = torch.cuda.current_stream(jobs[0][0].device)
+            grouped = GROUP_SMALL_DW and all(dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 for dy, x, _ in jobs)
+            if grouped:
+                # ONE launch per 16 queued weight gradients (hriemo_gemm_bf16_group_tn) instead of one ~20 us launch each
+                table = [(dy.shape[1], x.shape[1], dy.shape[0], dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                          out.stride(0)) for dy, x, out in jobs]
+                host = torch.tensor(table, dtype=torch.int64)
+                _lib.call("hriemo_gemm_bf16_group_tn", host.data_ptr(), len(table), 1, _stream())
             for dy, x, out in jobs:
                 M, N = dy.shape
-                gemm(1, 1, N, x.shape[1], M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True, accumulate=True)
+                if not grouped:
+                    gemm(1, 1, N, x.shape[1], M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True, accumulate=True)
                 if CAPTURING:
                     self.keep.extend((dy, x, out))      # a captured graph keeps reading these buffers on every replay
                 else:

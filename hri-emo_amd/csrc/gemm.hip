@@ -18,14 +18,16 @@
 //    full-line 16-byte stores, fp32 (weight-gradient) tiles as 16-byte stores from registers;
 //  * blockIdx is remapped (bijectively) so each XCD's L2 sees a contiguous range of tiles.
 #include "gemm_common.h"
+#include <string.h>
 
 // Persistent kernel: the grid is one (or two) blocks per CU; block b belongs to XCD b & 7 and walks that XCD's
 // contiguous range of work units, so neighbouring tiles (same A row-panel) share an L2.  The operand ring is
 // one continuous stream over (tile, K-step): the first NS-1 stages of the NEXT tile are issued during the last
 // K-steps of the current one, the epilogue does not touch the ring and does not wait for its stores, so a
 // tile boundary costs neither a block launch, nor a cold prologue, nor a store drain.
+// (the body is a device function: gemm_kernel runs it on its one problem, gemm_group_kernel on problem blockIdx.y of a list)
 template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p) {
   constexpr int NWAVE = WM * WN;
   // 32-deep stages: 8-wave blocks run the staggered two-group schedule; 4-wave blocks (two per CU, whose waves pair
   // up on the SIMDs and drift apart on their own) the same K-step body without the second barrier
@@ -418,6 +420,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_ker
   leave();
 }
 
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_kernel(const GemmArgs p) {
+  gemm_body<TA, TB, OUTF32, BM, BN, WM, WN, NS, BK>(p);
+}
+
+// Grouped launch: up to 16 independent problems of one layout / tile configuration, problem blockIdx.y walked statically by its
+// gridDim.x blocks (blocks beyond a problem's tile count leave at once).  The decoder's and the gate's weight-gradient GEMMs --
+// 16 latency-bound ~20 us launches for ~0.1 GFLOP each, queued by the host until the encoder's backward has room for them -- go
+// out as ONE launch.  The problem table travels in the kernel arguments (capture-safe).
+struct GemmGroup { GemmArgs p[16]; };
+template <int TA, int TB, int OUTF32, int BM, int BN, int WM, int WN, int NS, int BK>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_group_kernel(const GemmGroup grp) {
+  gemm_body<TA, TB, OUTF32, BM, BN, WM, WN, NS, BK>(grp.p[blockIdx.y]);
+}
+
 // out[m][n] (+)= sum_s ws[s][m][n], slabs summed in slice order (bit-identical from run to run).  Four slabs' loads are in
 // flight per lane before the first add (the k-loop is latency-bound otherwise: 0.5 TB/s measured on the 66 MB of a
 // 3072x768x7 reduction in round 1's form, profiles/r02_bench_kernel_stats.csv).
@@ -656,6 +673,53 @@ extern "C" int hriemo_gemm_bf16_split(int ta, int tb, int M, int N, int K, const
   HRIEMO_CHECK(C2 != nullptr, "gemm_split: second output missing");
   return gemm_impl(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, 1, nullptr, 0, nullptr, 0, accumulate, workspace, workspace_bytes, nullptr, st,
                    C2, ldc2, split_m);
+}
+// Weight-gradient GEMMs C_j[N_j, K_j] (+)= dY_j[M_j, N_j]^T . X_j[M_j, K_j] (fp32 results) of njobs independent problems in one launch
+// per 16 problems.  jobs_host: njobs x 9 int64 {M (output rows), N (output columns), K (reduction rows), A, lda, B, ldb, C, ldc}
+// in hriemo_gemm_bf16's (ta = 1, tb = 1) convention.  No split-K: meant for short reductions (K <= a few thousand rows).
+extern "C" int hriemo_gemm_bf16_group_tn(const void* jobs_host, int njobs, int accumulate, hipStream_t st) {
+  HRIEMO_CHECK(jobs_host != nullptr && njobs > 0, "gemm_group: empty job table");
+  const long long* h = (const long long*)jobs_host;
+  constexpr int BM = 128, BN = 128;
+  using KernelT = void (*)(const GemmGroup);
+  KernelT kern = gemm_group_kernel<1, 1, 1, BM, BN, 2, 2, 2, 64>;
+  const int lds = kCfg[0].lds + 4 * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  for (int j0 = 0; j0 < njobs; j0 += 16) {
+
+    GemmGroup g = {};
+    const int nj = njobs - j0 < 16 ? njobs - j0 : 16;
+    int gx = 1;
+    double flops = 0.0;
+    for (int j = 0; j < nj; ++j) {
+      const long long* r = h + (long)(j0 + j) * 9;
+      GemmArgs& a = g.p[j];
+      a.M = (int)r[0]; a.N = (int)r[1]; a.K = (int)r[2];
+      a.A = (const bf16_t*)r[3]; a.lda = (long)r[4]; a.B = (const bf16_t*)r[5]; a.ldb = (long)r[6]; a.C = (void*)r[7]; a.ldc = (long)r[8];
+      HRIEMO_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.M % 8 == 0 && a.N % 8 == 0, "gemm_group: job %d: bad shape %dx%dx%d", j0 + j, a.M, a.N, a.K);
+      HRIEMO_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 4 == 0 && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0 &&
+                       ((uintptr_t)a.C % 16) == 0 && a.lda < (1L << 21) && a.ldb < (1L << 21), "gemm_group: job %d: alignment", j0 + j);
+      HRIEMO_CHECK(a.K > (kCfg[0].ns - 2) * kCfg[0].bk, "gemm_group: job %d: reduction too short for the operand ring", j0 + j);
+      a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+      a.splitk = 1; a.k_per_split = (a.K + 63) / 64 * 64;
+      a.accumulate = accumulate; a.sched = nullptr;
+      const int tiles = a.tiles_m * a.tiles_n;
+      if (tiles > gx) gx = tiles;
+      flops += 2.0 * a.M * a.N * a.K;
+    }
+    for (int j = nj; j < 16; ++j) { g.p[j] = g.p[0]; g.p[j].tiles_m = 0; g.p[j].tiles_n = 0; }      // never launched (grid.y = nj)
+    const int cap = 2 * hriemo_num_cus();                 // a problem's tiles beyond its blocks are walked statically
+    if (gx > cap) gx = cap;
+    hriemo_prof_begin(HP_GEMM_TN, st);
+    hipLaunchKernelGGL(kern, dim3(gx, nj), dim3(256), lds, st, g);
+    HRIEMO_LAUNCH_CHECK("gemm_group_kernel");
+    hriemo_prof_end(HP_GEMM_TN, st, flops);
+  }
+  return 0;
 }
 extern "C" int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                                        void* C, long ldc, const void* aux, long ldaux, float* colsum_partials, hipStream_t st) {

@@ -44,6 +44,12 @@ int hriemo_gemm_bf16(int ta, int tb, int M, int N, int K, const void* A, long ld
                      void* C, long ldc, int c_is_f32, const float* bias, int epilogue, const void* aux,
                      long ldaux, int accumulate, float* workspace, long workspace_bytes, hriemo_stream_t stream);
 
+/* njobs independent weight-gradient GEMMs C_j[M_j, N_j] (+)= A_j[K_j, M_j]^T . B_j[K_j, N_j] (layout ta = 1, tb = 1 of
+ * hriemo_gemm_bf16, fp32 results, no split-K) in ONE launch per 16 problems: jobs_host = HOST array of njobs x 9 int64
+ * {M, N, K, A, lda, B, ldb, C, ldc}, passed through kernel arguments (capture-safe).  The decoder's and the gate's weight gradients
+ * (models/emotion_decoder.py:14-27, models/beta_gate_tacfn.py:62-66: M = B*N_e or B reduction rows), 16 latency-bound launches
+ * per step otherwise. */
+int hriemo_gemm_bf16_group_tn(const void* jobs_host, int njobs, int accumulate, hriemo_stream_t stream);
 /* hriemo_gemm_bf16 with an fp32 result written to TWO matrices: rows [0, split_m) of the [M, N] result to C, rows [split_m, M) to
  * C2 (from its row 0).  The weight gradient of a projection whose weight rows belong to two parameters -- one N = 3d GEMM per
  * shared input: rows [0, d) are the Q rows of one nn.MultiheadAttention.in_proj_weight, rows [d, 3d) the K | V rows of another

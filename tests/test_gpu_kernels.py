@@ -121,6 +121,38 @@ def test_gemm_tn_split_output(ops, M, N, K, split):
     assert torch.equal(pa[:split].double().cpu(), ref[:split]) and torch.equal(pb[split:].double().cpu(), ref[split:])
 
 
+def test_gemm_group_tn_many_weight_gradients_in_one_launch(ops):
+    """hriemo_gemm_bf16_group_tn: the decoder's / gate's weight-gradient GEMMs (short reductions, 64 ... 1000 rows; outputs from
+    256 x 3072 down to 768 x 256, row slices of wider buffers, strided operands) as one grouped launch per 16 problems -- 19 problems
+    here, i.e. two launches -- exact on integers against torch, accumulating into non-zero destinations."""
+    from hri_emo_amd import _lib
+    shapes = [(384, 2304, 768), (384, 768, 768), (384, 768, 2048), (384, 2048, 768), (64, 768, 256), (64, 256, 3072), (1000, 136, 200),
+              (8, 64, 64), (384, 1536, 768)] * 2 + [(72, 8, 8)]
+    keep, table, want = [], [], []
+    for j, (K, M, N) in enumerate(shapes):                     # K reduction rows; result [M, N]
+        dy = torch.zeros((K, M + 16), dtype=torch.bfloat16, device="cuda")
+        dyv = ints((K, M), -2, 3, seed=50 + j)
+        dy[:, 8:8 + M] = dyv.cuda().bfloat16()
+        x = ints((K, N), -2, 3, seed=90 + j)
+        xd = x.cuda().bfloat16()
+        init = ints((M + 8, N), -1, 2, seed=130 + j)
+        out = init.clone().cuda()
+        keep += [dy, xd, out]
+        a = dy[:, 8:8 + M]
+        table.append((M, N, K, a.data_ptr(), a.stride(0), xd.data_ptr(), xd.stride(0), out[8:].data_ptr(), out.stride(0)))
+        want.append((out, init, dyv.t().double() @ x.double()))
+    host = torch.tensor(table, dtype=torch.int64)
+    _lib.call("hriemo_gemm_bf16_group_tn", host.data_ptr(), len(table), 1, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for out, init, ref in want:
+        assert torch.equal(out[:8].cpu(), init[:8])                                  # rows outside the destination untouched
+        assert torch.equal(out[8:].double().cpu(), init[8:].double() + ref)
+    _lib.call("hriemo_gemm_bf16_group_tn", host.data_ptr(), len(table), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for out, init, ref in want:
+        assert torch.equal(out[8:].double().cpu(), ref)                              # accumulate = 0 overwrites
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(200, 136, 96), (1000, 768, 256), (25600, 3072, 768), (8192, 3072, 768), (384, 2048, 768)])
 def test_gemm_masked_dx_with_column_sums(ops, cfg, M, N, K):
