@@ -8,6 +8,7 @@
 // workspace, then a fixed-order reduce) so results are bitwise reproducible.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define EPS_DEFAULT 1e-5f
 
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ beta gate
 // LayerNorm every row of X[b, :, :]; write the first Lkeep rows; pooled partial sums over valid rows.
-template <int NCH>
+template <int NCH, bool PF>
 __global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restrict__ X, const float* __restrict__ X32, const uint8_t* __restrict__ mask,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ Yn, float* __restrict__ mean_o, float* __restrict__ rstd_o,
@@ -469,19 +470,32 @@ __global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restri
   constexpr bool HOIST = NCH <= 4;
   float gm8[HOIST ? NCH : 1][8], bt8[HOIST ? NCH : 1][8];
   if (HOIST) { load_cols<HOIST ? NCH : 1>(gamma, d >> 3, threadIdx.x & 63, gm8); load_cols<HOIST ? NCH : 1>(beta, d >> 3, threadIdx.x & 63, bt8); }
-  for (int l = chunk * 32 + wave; l < min(L, chunk * 32 + 32); l += 4) {
+  // a wave walks its 8 rows one after the other and every row is one trip to HBM: the NEXT row's loads are issued before this
+  // row's reductions, so the trips overlap (the kernel sat at 2 TB/s with one row in flight per wave)
+  const int lend = min(L, chunk * 32 + 32);
+  float nx[NCH][8];
+  auto load_row = [&](int l, float (&dst)[NCH][8]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) load_resid(X, X32, ((long)b * L + l) * d + ch * 8, dst[c]);
+    }
+  };
+  if (PF && chunk * 32 + wave < lend) load_row(chunk * 32 + wave, nx);
+  for (int l = chunk * 32 + wave; l < lend; l += 4) {
     const long row = (long)b * L + l;
     float s[NCH][8];
     float sum = 0.f;
+    if (!PF) load_row(l, nx);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nchunk) {
-        load_resid(X, X32, row * d + ch * 8, s[c]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += s[c][j];
+        for (int j = 0; j < 8; ++j) { s[c][j] = nx[c][j]; sum += s[c][j]; }
       }
     }
+    if (PF && l + 4 < lend) load_row(l + 4, nx);
     const float mu = wave_sum(sum) * invd;
     float sq = 0.f;
 #pragma unroll
@@ -723,6 +737,11 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
 }
 
 // ================================================================== host entry points
+static bool lnpool_prefetch() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("HRIEMO_LNPOOL_PREFETCH"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
 #define DISPATCH_NCH(d, CALL)                         \
   {                                                   \
     const int nch__ = ((d) / 8 + 63) / 64;            \
@@ -1114,7 +1133,12 @@ extern "C" int hriemo_ln_pool_fwd(const void* X, const float* X32, const unsigne
   HRIEMO_CHECK(Lkeep >= 0 && Lkeep <= L, "ln_pool_fwd: Lkeep=%d out of range (L=%d)", Lkeep, L);
   const int nc = (L + 31) / 32;
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((ln_pool_fwd_kernel<N>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, X32, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps)
+  // (next-row prefetch for d <= 1024, where it fits the registers: HRIEMO_LNPOOL_PREFETCH=0 switches it off)
+#define CALL(N)                                                                                                                  \
+  if ((N) <= 2 && lnpool_prefetch())                                                                                             \
+    hipLaunchKernelGGL((ln_pool_fwd_kernel<N, ((N) <= 2)>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, X32, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps); \
+  else                                                                                                                           \
+    hipLaunchKernelGGL((ln_pool_fwd_kernel<N, false>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, X32, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_fwd_kernel");
