@@ -240,7 +240,9 @@ class CrossModalTransformer(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([CrossModalBlock(d_model, n_heads, dropout) for _ in range(num_layers)])
 
-    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need):
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, after_first_layer=None):
+        """after_first_layer: called once the first layer is enqueued (FusionWithEmotionDecoder launches the gate / decoder
+        weight casts there, behind the first layer's text branch instead of in front of the whole step)"""
         all_layers_attn = []
         plan = None
         _ops.FLUSH_SITES.add(self.layers[0]._site[1])        # layer-0 text self-attention: the last text-branch backward (_ops._DeferredWgrad)
@@ -252,10 +254,12 @@ class CrossModalTransformer(nn.Module):
             if sa is not None and st is not None:
                 plan = (sa, st)
                 a, a32, t, t32 = _ops.pack_rows(a, sa), _ops.pack_rows(a32, sa), _ops.pack_rows(t, st), _ops.pack_rows(t32, st)
-        for layer in self.layers:
+        for i, layer in enumerate(self.layers):
             a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need, plan)
             if need:
                 all_layers_attn.append(maps)
+            if i == 0 and after_first_layer is not None:
+                after_first_layer()
         if plan is not None:
             a, a32 = _ops.unpack_rows(a, plan[0]), _ops.unpack_rows(a32, plan[0])
             t, t32 = _ops.unpack_rows(t, plan[1]), _ops.unpack_rows(t32, plan[1])

@@ -19,6 +19,12 @@ _PREFETCH = _os.environ.get("HRIEMO_PREFETCH_SHADOWS", "1") != "0"
 # the graph runtime starts the audio branch late either way, and two bandwidth-heavy bursts at the top cost more than the small
 # casts that hide in gaps later.  Opt-in.
 _BATCHED_CASTS = _os.environ.get("HRIEMO_BATCHED_CASTS", "0") == "1"
+# where the gate / decoder casts are enqueued: in front of the step (0) or behind the first fusion layer (1).  In front, the
+# graph runtime runs those 14 side-stream launches and the text branch's first kernels before it starts the audio branch, whose
+# first GEMM begins ~300 us into the replay; behind the first layer the audio GEMM starts at 85 us -- and the text branch then
+# starts at 310 us instead: the encoder forward ends 20 us earlier and the step is unchanged (7.90 / 7.93 vs 7.91 / 7.92 ms,
+# same box).  The top of the step is not idle time, it is the text branch running first.  Opt-in.
+_PREFETCH_LATE = _os.environ.get("HRIEMO_PREFETCH_LATE", "0") == "1"
 
 
 class FusionWithEmotionDecoder(nn.Module):
@@ -38,7 +44,7 @@ class FusionWithEmotionDecoder(nn.Module):
             if hasattr(m, "batch_offset"):
                 m.batch_offset = int(offset)
 
-    def _prefetch_shadows(self, device):
+    def _prefetch_shadows(self, device, late=False):
         """bf16 copies of EVERY weight matrix of the step from two batched cast launches at the top of the step: the first
         fusion layer's on the caller's stream (its GEMMs come first), everything else -- further layers, gate, decoder -- on the
         side stream beside them.  Before: one ~5 us cast launch per matrix, 16 of them a serial chain on the side stream that
@@ -62,7 +68,8 @@ class FusionWithEmotionDecoder(nn.Module):
                 _ops.cast_batch(jobs)
             return None
         main = torch.cuda.current_stream(device)
-        _ops.fork(side, main)                       # the masters may have just been updated on the caller's stream
+        if not late:                                # late: the side stream is already behind the caller's stream (the first layer's fork)
+            _ops.fork(side, main)                   # the masters may have just been updated on the caller's stream
         with torch.cuda.stream(side):
             if batched:
                 jobs = []
@@ -123,14 +130,21 @@ class FusionWithEmotionDecoder(nn.Module):
         a, a32 = _ops.as_pair(h_a)
         t, t32 = _ops.as_pair(h_t)
         _ops.begin_step()
-        ready = self._prefetch_shadows(a.device)
+        late = _PREFETCH_LATE and not _BATCHED_CASTS and len(self.cross_modal.layers) > 0
+        ready = [None if late else self._prefetch_shadows(a.device)]
+        dev = a.device
+
+        def prefetch_late():
+            ready[0] = self._prefetch_shadows(dev, late=True)
+
         _ops.JOIN_SCOPE += 1          # logits, beta and z all depend on both branches: the encoder's gradient joins are safe
         try:
-            a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
+            a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need,
+                                                                       prefetch_late if late else None)
         finally:
             _ops.JOIN_SCOPE -= 1
-        if ready is not None:
-            torch.cuda.current_stream(a.device).wait_event(ready)
+        if ready[0] is not None:
+            torch.cuda.current_stream(a.device).wait_event(ready[0])
         h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)
         fused_mask = self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
         z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype)

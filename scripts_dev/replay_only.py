@@ -16,6 +16,13 @@ opt = FusedClipAdamW(dp.buckets, lr=1e-4, weight_decay=1e-2, max_norm=5.0)
 B = 64
 dp.set_global_batch(B)
 batch = bench.synth(B, 0, dev)
+if os.environ.get("RAGGED", "0") == "1":      # bench.py's ragged leg: valid length ~U[L/2, L] per sample and modality
+    g = torch.Generator().manual_seed(4321)
+    la = torch.randint(bench.T_A // 2, bench.T_A + 1, (B,), generator=g)
+    lt = torch.randint(bench.T_T // 2, bench.T_T + 1, (B,), generator=g)
+    batch = (batch[0], batch[1], (torch.arange(bench.T_A)[None] >= la[:, None]).to(dev), (torch.arange(bench.T_T)[None] >= lt[:, None]).to(dev), batch[4])
+if os.environ.get("VARLEN", "0") == "1":
+    H.set_varlen(True)
 dp.step(*batch)                   # eager once: sizes workspaces
 if os.environ.get("EAGER", "0") != "1":
     dp.capture(*batch)
