@@ -36,7 +36,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
   constexpr int A_PW = A_BYTES / 1024 / NWAVE, B_PW = B_BYTES / 1024 / NWAVE, LPT = A_PW + B_PW;
   constexpr int MT = BM / WM / 16, NTL = BN / WN / 16;
   static_assert(A_PW * NWAVE * 1024 == A_BYTES && B_PW * NWAVE * 1024 == B_BYTES, "tile must split evenly over waves");
-  static_assert(NS >= 2 && NS <= 4 && (NS - 1) * LPT < 64, "ring depth / vmcnt range");
+  static_assert(NS >= 2 && NS <= 8 && (NS - 1) * LPT < 64, "ring depth / vmcnt range");
   static_assert(!STAG || NS == 4, "staggered schedule: 4 ring slots");
   static_assert(!K32 || NS >= 3, "32-deep stages need a ring of 3");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,7 +175,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
     // groups of LPT loads younger than stage it+1 when iteration `it` retires it
     auto retire_next = [&](int it) {
       const int young = has_next ? NS - 2 : min(NS - 2, max(0, nk - it - 2));
-      if (NS >= 4 && young >= 2) wait_vmcnt<(NS >= 4 ? 2 : 0) * LPT>();
+      if (NS >= 8 && young >= 6) wait_vmcnt<(NS >= 8 ? 6 : 0) * LPT>();
+      else if (NS >= 7 && young >= 5) wait_vmcnt<(NS >= 7 ? 5 : 0) * LPT>();
+      else if (NS >= 6 && young >= 4) wait_vmcnt<(NS >= 6 ? 4 : 0) * LPT>();
+      else if (NS >= 5 && young >= 3) wait_vmcnt<(NS >= 5 ? 3 : 0) * LPT>();
+      else if (NS >= 4 && young >= 2) wait_vmcnt<(NS >= 4 ? 2 : 0) * LPT>();
       else if (NS >= 3 && young >= 1) wait_vmcnt<(NS >= 3 ? 1 : 0) * LPT>();
       else wait_vmcnt<0>();
     };
@@ -475,6 +479,9 @@ static const TileCfg kCfg[] = {
     {64, 128, 256, 4 * 24576, 4, 64},    // 3: 64x128, 2x2 waves (32x64 per wave), 4 stages: small-M, latency-bound problems
     {256, 256, 512, 4 * 32768, 4, 32},   // 4: 256x256, 2x4 waves, 4 stages of 32 k, staggered two-group schedule
     {320, 128, 512, 2 * 57344, 2, 64},   // 5: 320x128, 4x2 waves (80x64 per wave), 2 stages: tile count for M = 25600, N = 768
+    {64, 128, 256, 6 * 24576, 6, 64},    // 6: config 3 with a 6-deep ring: the M = 384 decoder chain is bound by memory latency / prefetch depth
+    {32, 128, 256, 7 * 20480, 7, 64},    // 7: 32x128, 2x2 waves (16x64 per wave), 7-deep ring: twice the blocks, deeper prefetch
+    {32, 64, 128, 6 * 12288, 6, 64},     // 8: 32x64, 2x1 waves (16x64 per wave): least operand bytes per CU
 };
 static const int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 int hriemo_num_cus() {
@@ -548,6 +555,15 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
     case 5:
       if constexpr (TA == 0 && OUTF32 == 0) launch_one<TA, TB, OUTF32, 320, 128, 4, 2, 2>(a, lds, st);   // row-major A only
       break;
+    case 6:
+      if constexpr (TA == 0) launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 6>(a, lds, st);
+      break;
+    case 7:
+      if constexpr (TA == 0) launch_one<TA, TB, OUTF32, 32, 128, 2, 2, 7>(a, lds, st);
+      break;
+    case 8:
+      if constexpr (TA == 0 && TB == 0) launch_one<TA, TB, OUTF32, 32, 64, 2, 1, 6>(a, lds, st);   // 128-B k-rows cannot hold the K-strided swizzle
+      break;
     default: launch_one<TA, TB, OUTF32, 64, 128, 2, 2, 4>(a, lds, st); break;
   }
 }
@@ -558,7 +574,15 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
 static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
-  if (M < 1024 || N < 256) return (M <= 512 && N >= 256) ? 3 : 0;               // decoder / gate sized problems
+  if (M < 1024 || N < 256) {                                                    // decoder / gate sized problems
+    // one block per CU pulls ~68 GB/s of operands whatever the ring depth (scripts_dev/bench_small_gemm.py: 0.375 us per 24 KB
+    // K-step on the 64x128 tile, the same with a 6-deep ring), so these launches are as fast as their largest block's operand
+    // bytes are small: 32-row tiles, 64 columns where that still fits one round of CUs and the B operand is K-contiguous
+    if (!(M <= 512 && N >= 256)) return 0;
+    static const bool wide = [] { const char* e = getenv("HRIEMO_SMALL_GEMM_WIDE"); return e && e[0] == '1'; }();   // A/B: the 64x128 tile
+    if (K <= 384 || wide) return 3;
+    return (tb == 0 && N <= 1024) ? 8 : 7;
+  }
   // (config 5, 320x128: 480 instead of 600 tiles for the 25600 x 768 outputs, is 3-8 % faster on those launches alone
   // but 0.1 ms slower inside the two-stream step -- kept as a tuning configuration, never picked)
   if (tb == 0) return (N >= 2048 && M >= 16384) ? 2 : 1;                       // NT
@@ -567,13 +591,14 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
 
 // rows of the column-sum partials of hriemo_gemm_bf16_colsum: one per wave row-block of the tile configuration the launch takes
 static int wave_rows(int cfg) {
-  static const int waves_m[] = {2, 4, 2, 2, 2, 4};
+  static const int waves_m[] = {2, 4, 2, 2, 2, 4, 2, 2, 2};
   return kCfg[cfg].bm / waves_m[cfg];
 }
 static int pick_config(int ta, int tb, int M, int N, int K);
 extern "C" int hriemo_gemm_colsum_rows(int ta, int tb, int M, int N, int K) {
   int cfg = pick_config(ta, tb, M, N, K);
-  if (cfg == 3 && ta == 1) cfg = 0;
+  if (cfg == 8 && tb == 1) cfg = 7;
+  if ((cfg == 3 || cfg >= 6) && ta == 1) cfg = 0;
   if (cfg == 5 && ta == 1) cfg = 0;
   if (K <= (kCfg[cfg].ns - 2) * kCfg[cfg].bk) cfg = 0;
   const int wr = wave_rows(cfg);
@@ -600,7 +625,8 @@ static int gemm_impl(int ta, int tb, int M, int N, int K, const void* A, long ld
   HRIEMO_CHECK(c_is_f32 || !accumulate, "gemm: accumulate needs fp32 output");
 
   int cfg = pick_config(ta, tb, M, N, K);
-  if (cfg == 3 && ta == 1) cfg = 0;            // the 64-row tile has no K-strided A image (128-B rows cannot hold the swizzle)
+  if (cfg == 8 && tb == 1) cfg = 7;
+  if ((cfg == 3 || cfg >= 6) && ta == 1) cfg = 0;   // the 64- / 32-row tiles have no K-strided A image (128-B rows cannot hold the swizzle)
   if (cfg == 5 && (ta == 1 || c_is_f32)) cfg = 0;   // the 320-row tile exists for row-major A and bf16 output only
   GemmArgs a = {};
   a.M = M; a.N = N; a.K = K;
