@@ -52,6 +52,7 @@ _SIGS = {
     "hriemo_cast_f32_to_bf16": ("pplp", "i"),
     "hriemo_cast_bf16_to_f32": ("pplp", "i"),
     "hriemo_cast_f32_to_bf16_batch": ("pip", "i"),
+    "hriemo_cast_copy_batch": ("pip", "i"),
     "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
     "hriemo_expand_rows": ("ppilp", "i"),
     "hriemo_rowdot_fwd": ("pppppiip", "i"),

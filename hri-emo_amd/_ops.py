@@ -12,6 +12,7 @@ libhriemo.so.  Activations are bf16, statistics/parameter gradients fp32.  No CP
 """
 import itertools
 import math
+import os as _os
 
 import torch
 import torch.nn.functional as F
@@ -153,9 +154,10 @@ STEP_ID = 0                # bumped at the top of every model step (begin_step):
 
 
 def begin_step():
-    global STEP_ID
+    global STEP_ID, _last_heavy_attn
     STEP_ID += 1
     _half_reports.clear()
+    _last_heavy_attn = None
 
 WEIGHTS_EPOCH = 0          # bumped by anything that rewrites parameter storage behind autograd's back (optim.FusedClipAdamW
                            # updates the flat buffer through raw pointers: p._version and p.data_ptr() do not move)
@@ -278,6 +280,45 @@ class Shadows:
             ent = (ver, s, STEP_ID)
             self._d[key] = ent
         return ent[1]
+
+    def get_cat_wb(self, wparts, bparts):
+        """get_cat(wparts) and get_cat_vec(bparts) refreshed together by ONE launch (hriemo_cast_copy_batch) -- a shared
+        projection's [3d, d] bf16 weight shadow and [3d] fp32 bias; before: two casts, a torch.cat and a copy per refresh."""
+        kw = ("cat",) + tuple((id(p), r0, r1) for p, r0, r1 in wparts)
+        kb = ("catv",) + tuple((id(p), r0, r1) for p, r0, r1 in bparts)
+        ew, eb = self._d.get(kw), self._d.get(kb)
+        vw = tuple((p._version, p.data_ptr()) for p, _, _ in wparts) + (WEIGHTS_EPOCH,)
+        vb = tuple((p._version, p.data_ptr()) for p, _, _ in bparts) + (WEIGHTS_EPOCH,)
+        dev = wparts[0][0].device
+        stale_w = (CAPTURING and (ew is None or ew[2] != STEP_ID)) or ew is None or ew[0] != vw or ew[1].device != dev
+        stale_b = (CAPTURING and (eb is None or eb[2] != STEP_ID)) or eb is None or eb[0] != vb or eb[1].device != dev
+        if not (stale_w or stale_b):
+            return ew[1], eb[1]
+        if not all(p.is_contiguous() for p, _, _ in wparts + bparts):
+            return self.get_cat(wparts), self.get_cat_vec(bparts)
+        K = wparts[0][0].shape[1]
+        rows = sum(r1 - r0 for _, r0, r1 in wparts)
+        nb = sum(r1 - r0 for _, r0, r1 in bparts)
+        sw = ew[1] if ew is not None and ew[1].device == dev and ew[1].shape == (rows, K) else torch.empty((rows, K), dtype=BF16, device=dev)
+        sb = eb[1] if eb is not None and eb[1].device == dev and eb[1].shape == (nb,) else torch.empty((nb,), dtype=torch.float32, device=dev)
+        jobs, at = [], 0
+        for p, r0, r1 in wparts:
+            _require_gpu(p)
+            _require_fp32_master(p)
+            jobs.append((p.data_ptr() + r0 * K * 4, sw.data_ptr() + at * K * 2, (r1 - r0) * K, 0))
+            at += r1 - r0
+        at = 0
+        for p, r0, r1 in bparts:
+            _require_fp32_master(p)
+            jobs.append((p.data_ptr() + r0 * 4, sb.data_ptr() + at * 4, r1 - r0, 1))
+            at += r1 - r0
+        if any(j[0] % 16 or j[1] % 16 for j in jobs):
+            return self.get_cat(wparts), self.get_cat_vec(bparts)
+        host = torch.tensor(jobs, dtype=torch.int64)
+        _lib.call("hriemo_cast_copy_batch", host.data_ptr(), len(jobs), _stream())
+        self._d[kw] = (vw, sw, STEP_ID)
+        self._d[kb] = (vb, sb, STEP_ID)
+        return sw, sb
 
     def get_cat_vec(self, parts):
         """fp32 concatenation of bias slices ((param, r0, r1), ...), cached like the weight shadows"""
@@ -662,6 +703,16 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=Fal
     return (o, lse, mb) if want_bits else (o, lse)
 
 
+# The single-pass attention backward kernels hold 80-150 KB of LDS per workgroup.  Two of them launched side by side from the two
+# branch streams (t2a's query-resident kernel and a2t's key-resident one become ready together) split every CU's LDS between them
+# and ran 218 us for the pair against 70 + 62 us one after the other (gpurun_out/tl/full_step.txt, round 3).  With
+# HRIEMO_ATTN_BWD_SERIAL=1 such a launch waits for the previous one of the other stream -- measured neutral on the whole step
+# (7.96 / 7.97 / 7.98 vs 7.94 / 7.95 / 7.99 ms, same box: the step is bound by the sum of its kernels' work, not by which of them
+# overlap), so it stays opt-in.
+ATTN_BWD_SERIAL = _os.environ.get("HRIEMO_ATTN_BWD_SERIAL", "0") == "1"
+_last_heavy_attn = None
+
+
 def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None, mask_bits=None, cu=None):
     """bias_grad = (db_q [d], db_kv [2d]) fp32 views the column sums of dQ and dK|dV go to: the kernels leave per-block partial
     sums behind (fp32 values before the bf16 rounding of dQ/dK/dV); inside backward with the fused path they are finished by the
@@ -675,6 +726,12 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
         rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_kv_colsum_rows(B, H, Lq, Lk, hd)
         pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
         pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
+    global _last_heavy_attn
+    heavy = ATTN_BWD_SERIAL and q.is_cuda and bool(_lib.lib().hriemo_attn_bwd_single_pass_q(B, H, Lq, Lk, hd)
+                                                   or _lib.lib().hriemo_attn_bwd_single_pass(B, H, Lk, hd))
+    cur_s = torch.cuda.current_stream(q.device) if heavy else None
+    if heavy and _last_heavy_attn is not None and _last_heavy_attn[1] != cur_s:
+        cur_s.wait_event(_last_heavy_attn[0])
     if cu is not None:
         _lib.call("hriemo_attn_bwd_varlen", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
                   _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(cu[0]), _p(cu[1]),
@@ -685,6 +742,10 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
                   _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
                   _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
                   _p(pq), _p(pkv), _p(mask_bits), _stream())
+    if heavy:
+        ev = torch.cuda.Event()
+        ev.record(cur_s)
+        _last_heavy_attn = (ev, cur_s)
     if fold:
         d = H * hd
         deferred = bias_grad[2] if len(bias_grad) > 2 else False
@@ -766,7 +827,6 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
     return dx, dg, outs[0], outs[1], outs[2]
 
 
-import os as _os
 TWIN = _os.environ.get("HRIEMO_FP32_TWIN", "1") != "0"      # carry the fp32 twin of the residual stream (LayerNorm outputs)
 
 
@@ -1384,8 +1444,7 @@ class SharedProjFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)      # a half nobody differentiated must arrive as None, not as zeros
         B, L, d = x.shape
         x2 = _contig_bf16(x).view(B * L, d)
-        wcat = sh.get_cat(((wq, 0, d), (wkv, d, 3 * d)))
-        bcat = sh.get_cat_vec(((bq, 0, d), (bkv, d, 3 * d)))
+        wcat, bcat = sh.get_cat_wb(((wq, 0, d), (wkv, d, 3 * d)), ((bq, 0, d), (bkv, d, 3 * d)))
         out = linear_fwd(x2, wcat, bcat)
         ctx.save_for_backward(x2, wcat)
         ctx.cfg = (B, L, d)

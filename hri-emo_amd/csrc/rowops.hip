@@ -919,13 +919,23 @@ extern "C" int hriemo_cast_f32_to_bf16(const float* src, void* dst, long n, hipS
 // dependent ~5 us launches, 16 of them a serial chain in front of the step's first GEMM (profiles/r03_step_timeline.txt).
 // Job j = (src, dst, n elements, first block): the table travels as a kernel argument (capture-safe, no staging buffer); a
 // block finds its job by a linear scan (<= 64 entries) and casts a 2048-element span of it.
-struct CastJobs { const float* src[64]; bf16_t* dst[64]; long n[64]; int first[65]; int njobs; };
+struct CastJobs { const float* src[64]; void* dst[64]; long n[64]; int first[65]; int njobs; unsigned long long f32_copy; };
 __global__ __launch_bounds__(256) void cast_f32_bf16_batch_kernel(const CastJobs J) {
   int j = 0;
   while (j + 1 < J.njobs && (int)blockIdx.x >= J.first[j + 1]) ++j;
   const long n = J.n[j], base = ((long)blockIdx.x - J.first[j]) * 2048 + (long)threadIdx.x * 8;
   const float* src = J.src[j];
-  bf16_t* dst = J.dst[j];
+  if ((J.f32_copy >> j) & 1ull) {            // job kind 1: fp32 -> fp32 (bias slices into a concatenated vector)
+    float* dst = (float*)J.dst[j];
+    if (base + 8 <= n) {
+      *(f32x4*)(dst + base) = *(const f32x4*)(src + base);
+      *(f32x4*)(dst + base + 4) = *(const f32x4*)(src + base + 4);
+    } else {
+      for (long e = base; e < n; ++e) dst[e] = src[e];
+    }
+    return;
+  }
+  bf16_t* dst = (bf16_t*)J.dst[j];
   if (base + 8 <= n) {
     const f32x4 a = *(const f32x4*)(src + base), b = *(const f32x4*)(src + base + 4);
     float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -934,18 +944,18 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_batch_kernel(const CastJobs
     for (long e = base; e < n; ++e) dst[e] = (bf16_t)src[e];
   }
 }
-// jobs_host: njobs records of 3 x int64 {src, dst, n}; src / dst 16-byte aligned
-extern "C" int hriemo_cast_f32_to_bf16_batch(const void* jobs_host, int njobs, hipStream_t st) {
-  HRIEMO_CHECK(jobs_host != nullptr && njobs > 0, "cast_batch: empty job table");
-  const long long* h = (const long long*)jobs_host;
+static int cast_batch_impl(const long long* h, int njobs, int rec, hipStream_t st) {
   for (int j0 = 0; j0 < njobs; j0 += 64) {
     CastJobs J;
     const int nj = njobs - j0 < 64 ? njobs - j0 : 64;
     int blocks = 0;
+    J.f32_copy = 0ull;
     for (int j = 0; j < nj; ++j) {
-      const long long* r = h + (long)(j0 + j) * 3;
+      const long long* r = h + (long)(j0 + j) * rec;
       HRIEMO_CHECK(r[2] > 0 && (r[0] % 16) == 0 && (r[1] % 16) == 0, "cast_batch: job %d empty or unaligned", j0 + j);
-      J.src[j] = (const float*)r[0]; J.dst[j] = (bf16_t*)r[1]; J.n[j] = (long)r[2];
+      HRIEMO_CHECK(rec == 3 || r[3] == 0 || r[3] == 1, "cast_batch: job %d has kind %lld (0 = fp32 -> bf16, 1 = fp32 copy)", j0 + j, r[3]);
+      J.src[j] = (const float*)r[0]; J.dst[j] = (void*)r[1]; J.n[j] = (long)r[2];
+      if (rec == 4 && r[3] == 1) J.f32_copy |= 1ull << j;
       J.first[j] = blocks;
       blocks += (int)((r[2] + 2047) / 2048);
     }
@@ -956,6 +966,17 @@ extern "C" int hriemo_cast_f32_to_bf16_batch(const void* jobs_host, int njobs, h
     hriemo_prof_end(HP_ROWOPS, st, 0.0);
   }
   return 0;
+}
+// jobs_host: njobs records of 3 x int64 {src, dst, n}; src / dst 16-byte aligned
+extern "C" int hriemo_cast_f32_to_bf16_batch(const void* jobs_host, int njobs, hipStream_t st) {
+  HRIEMO_CHECK(jobs_host != nullptr && njobs > 0, "cast_batch: empty job table");
+  return cast_batch_impl((const long long*)jobs_host, njobs, 3, st);
+}
+// jobs_host: njobs records of 4 x int64 {src, dst, n, kind}; kind 0 = fp32 -> bf16, 1 = fp32 -> fp32.  One launch refreshes a
+// shared projection's concatenated weight shadow AND its concatenated bias vector (before: two casts, a cat and a copy).
+extern "C" int hriemo_cast_copy_batch(const void* jobs_host, int njobs, hipStream_t st) {
+  HRIEMO_CHECK(jobs_host != nullptr && njobs > 0, "cast_copy_batch: empty job table");
+  return cast_batch_impl((const long long*)jobs_host, njobs, 4, st);
 }
 extern "C" int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hipStream_t st) {
   HRIEMO_CHECK(n > 0, "cast: empty");

@@ -85,8 +85,11 @@ class CrossModalBlock(nn.Module):
                   self.ffn_t[2].weight):
             sh.plan(w, jobs)
 
-    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, plan=None):
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, plan=None, side_hook=None):
         """(bf16, fp32-twin) pairs in and out; returns (a, a32, t, t32, maps|None).
+        side_hook: called ON the side stream once the text branch's self-attention stage is enqueued -- where that stream waits
+        for the audio branch anyway (FusionWithEmotionDecoder runs the decoder's encoder-independent prologue there); only the
+        two-stream paths call it.
         plan = (Seq audio, Seq text): a / t hold the packed valid rows ([1, N, d], _ops.pack_rows) and the attention kernels get
         cu_seqlens instead of padding masks."""
         B, La, _ = a.shape
@@ -144,7 +147,10 @@ class CrossModalBlock(nn.Module):
                 with torch.cuda.stream(side):
                     t_s_, t_s32_, w_t_ = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
                     jt_ = join_for(t_s_)
-                    return (t_s_, t_s32_, w_t_, jt_) + self._shared_proj(t_s_, self.attn_t2a, self.attn_a2t, jt_)
+                    r_ = (t_s_, t_s32_, w_t_, jt_) + self._shared_proj(t_s_, self.attn_t2a, self.attn_a2t, jt_)
+                    if side_hook is not None:
+                        side_hook()
+                    return r_
 
             if not _AUDIO_FIRST:
                 t_s, t_s32, w_t, jt, q_t2a, kv_a2t, sgt = text_self()
@@ -197,6 +203,8 @@ class CrossModalBlock(nn.Module):
                 _ops.share(x_, side)
             with torch.cuda.stream(side):
                 t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
+                if side_hook is not None:
+                    side_hook()
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
             main.wait_stream(side)
             _ops.fork(side, main)
@@ -240,7 +248,7 @@ class CrossModalTransformer(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([CrossModalBlock(d_model, n_heads, dropout) for _ in range(num_layers)])
 
-    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, after_first_layer=None):
+    def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t, need, after_first_layer=None, side_hook=None):
         """after_first_layer: called once the first layer is enqueued (FusionWithEmotionDecoder launches the gate / decoder
         weight casts there, behind the first layer's text branch instead of in front of the whole step)"""
         all_layers_attn = []
@@ -255,7 +263,7 @@ class CrossModalTransformer(nn.Module):
                 plan = (sa, st)
                 a, a32, t, t32 = _ops.pack_rows(a, sa), _ops.pack_rows(a32, sa), _ops.pack_rows(t, st), _ops.pack_rows(t32, st)
         for i, layer in enumerate(self.layers):
-            a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need, plan)
+            a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need, plan, side_hook if i == 0 else None)
             if need:
                 all_layers_attn.append(maps)
             if i == 0 and after_first_layer is not None:

@@ -19,6 +19,12 @@ def _memory16(memory):
 
 import os as _os
 _HOIST_KV = _os.environ.get("HRIEMO_HOIST_KV", "1") != "0"
+# The first layer's query self-attention block (:42-43) reads the learned queries only, not the encoder: with HRIEMO_DECODER_PROLOGUE=1
+# FusionWithEmotionDecoder enqueues it on the side stream inside the first fusion layer, where that stream waits for the audio
+# branch, instead of on the decoder's chain behind the gate (EmotionDecoder._prologue); autograd replays its backward on that
+# stream.  Measured (round 3, same box, scripts_dev/replay_only.py 60): the gate -> loss span shrinks 406 -> 337 us and loss ->
+# gate backward 508 -> 458 us, the step 7.910 -> 7.894 ms: the launches cost elsewhere what they save in the tail.  Opt-in.
+_PROLOGUE = _os.environ.get("HRIEMO_DECODER_PROLOGUE", "0") == "1"
 
 
 class ExplainableDecoderLayer(nn.Module):
@@ -41,15 +47,26 @@ class ExplainableDecoderLayer(nn.Module):
         self._site = [_ops.new_site_base() for _ in range(3)]
         self.batch_offset = 0
 
-    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need, kv_pre=None, kv_ready=None):
+    def _self_block(self, tgt, tgt32):
+        """the query self-attention sub-layer (:42-43); -> (tgt, tgt32, the layer's dropout seed)"""
+        p = self.p if self.training else 0.0
+        seed = _ops.next_seed(self.training and p > 0)
+        sa = self.self_attn
+        tgt, tgt32, _ = _ops.SelfAttnLN.apply(tgt, tgt32, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
+                                              sa.out_proj.bias, self.norm1.weight, self.norm1.bias, self._sh,
+                                              self.nhead, None, p, seed, self._site[0], self.batch_offset, False)     # :42-43
+        return tgt, tgt32, seed
+
+    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need, kv_pre=None, kv_ready=None, self_done=None):
+        """self_done: the seed of this layer if tgt / tgt32 already ARE the self-attention sub-layer's output (EmotionDecoder._prologue)"""
         B, L, _ = memory.shape
         kpm = _ops.mask_u8(memory_key_padding_mask, B, L)
         p = self.p if self.training else 0.0
-        seed = _ops.next_seed(self.training and p > 0)
-        sa, ca, s = self.self_attn, self.cross_attn, self._site
-        tgt, tgt32, _ = _ops.SelfAttnLN.apply(tgt, tgt32, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
-                                              sa.out_proj.bias, self.norm1.weight, self.norm1.bias, self._sh,
-                                              self.nhead, None, p, seed, s[0], self.batch_offset, False)     # :42-43
+        ca, s = self.cross_attn, self._site
+        if self_done is None:
+            tgt, tgt32, seed = self._self_block(tgt, tgt32)
+        else:
+            seed = self_done
         if kv_ready is not None:          # K | V of the memory were projected on the side stream (EmotionDecoder._fwd)
             torch.cuda.current_stream(memory.device).wait_event(kv_ready)
         tgt, tgt32, w = _ops.CrossAttnLN.apply(tgt, tgt32, memory, ca.in_proj_weight, ca.in_proj_bias,
@@ -83,11 +100,37 @@ class EmotionDecoder(nn.Module):
                                      for _ in range(num_layers)])
         self.out_proj = nn.Linear(d_model, 1) if use_output_layer else None
 
-    def _fwd(self, memory16, memory_key_padding_mask, need, out_dtype):
-        B = memory16.size(0)
+    def _queries(self, B):
         out = _ops.ExpandFn.apply(self.emotion_queries, B)                                                # :127
         # fp32 twin of the broadcast queries (residual operand of the first layer; gradient flows via `out`)
         out32 = self.emotion_queries.detach().float().unsqueeze(0).expand(B, -1, -1).contiguous() if _ops.TWIN else None
+        return out, out32
+
+    def _prologue_applies(self, device):
+        return bool(_PROLOGUE and len(self.layers) > 0 and device.type == "cuda" and _ops.precision() == "bf16"
+                    and _ops.gemm_mode() == "bf16" and _ops.side_stream(device) is not None)
+
+    def _prologue(self, B, device):
+        """Everything of the decoder that does not depend on the encoder -- the broadcast queries and the first layer's query
+        self-attention block.  Called with the SIDE stream current (CrossModalBlock's side_hook: behind the text branch's first
+        self-attention stage, where that stream waits for the audio branch anyway; at the very top of the step the same launches
+        delayed the encoder by as much as they saved behind the gate); -> (tgt, tgt32, seed of layer 0, event) for _fwd(pre=...)."""
+        out, out32 = self._queries(B)
+        tgt, tgt32, seed = self.layers[0]._self_block(out, out32)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return tgt, tgt32, seed, ev
+
+    def _fwd(self, memory16, memory_key_padding_mask, need, out_dtype, pre=None):
+        B = memory16.size(0)
+        if pre is None:
+            out, out32 = self._queries(B)
+        else:
+            out, out32 = pre[0], pre[1]
+            main = torch.cuda.current_stream(memory16.device)
+            main.wait_event(pre[3])
+            _ops.share(out, main)
+            _ops.share(out32, main)
         all_layers_attn = []
         if _ops.want_mx_copy(memory16.shape[0] * memory16.shape[1], memory16.shape[2]):
             # fp8 GEMM mode: every layer projects the same memory to K | V -- quantise it once
@@ -114,7 +157,7 @@ class EmotionDecoder(nn.Module):
                 _ops.share(kv, main)
         for i, layer in enumerate(self.layers):
             out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need, kvs[i],
-                                                   ready if i == 0 else None)
+                                                   ready if i == 0 else None, pre[2] if (pre is not None and i == 0) else None)
             if need and attn_map is not None:
                 all_layers_attn.append(attn_map)
         logits = None

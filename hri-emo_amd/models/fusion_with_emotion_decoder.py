@@ -130,6 +130,16 @@ class FusionWithEmotionDecoder(nn.Module):
         a, a32 = _ops.as_pair(h_a)
         t, t32 = _ops.as_pair(h_t)
         _ops.begin_step()
+        # the decoder's memory mask needs the two padding masks only (L_fused = T_t, beta_gate_tacfn.py:98-116): built here, not on
+        # the decoder's serial chain behind the gate
+        fused_early = self._build_fused_mask(mask_a, mask_t, h_t.size(1))
+        pre = [None]
+        dec, nb = self.emotion_decoder, a.shape[0]
+
+        def decoder_prologue():             # runs on the side stream, inside the first fusion layer (cross_modal_block_tacfn side_hook)
+            pre[0] = dec._prologue(nb, dev)
+
+        hook = decoder_prologue if dec._prologue_applies(a.device) else None
         late = _PREFETCH_LATE and not _BATCHED_CASTS and len(self.cross_modal.layers) > 0
         ready = [None if late else self._prefetch_shadows(a.device)]
         dev = a.device
@@ -140,14 +150,14 @@ class FusionWithEmotionDecoder(nn.Module):
         _ops.JOIN_SCOPE += 1          # logits, beta and z all depend on both branches: the encoder's gradient joins are safe
         try:
             a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need,
-                                                                       prefetch_late if late else None)
+                                                                       prefetch_late if late else None, hook)
         finally:
             _ops.JOIN_SCOPE -= 1
         if ready[0] is not None:
             torch.cuda.current_stream(a.device).wait_event(ready[0])
         h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)
-        fused_mask = self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
-        z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype)
+        fused_mask = fused_early if h_fusion.size(1) == h_t.size(1) else self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
+        z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype, pre[0])
         if return_attention:
             return logits, beta, z, {"encoder": encoder_attns, "decoder": decoder_attns}
         return logits, beta, z

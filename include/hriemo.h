@@ -188,6 +188,10 @@ int hriemo_cast_bf16_to_f32(const void* src, float* dst, long n, hriemo_stream_t
 /* njobs casts in one launch (64 per launch): jobs_host = HOST array of njobs x 3 int64 {src fp32, dst bf16, n elements}, 16-byte
  * aligned pointers; the table is passed through kernel arguments (capture-safe).  The bf16 shadows of all weights of a step. */
 int hriemo_cast_f32_to_bf16_batch(const void* jobs_host, int njobs, hriemo_stream_t stream);
+/* the same with a kind per job: jobs_host = njobs x 4 int64 {src fp32, dst, n elements, kind}; kind 0 = fp32 -> bf16 (dst bf16),
+ * 1 = fp32 -> fp32 copy.  One launch refreshes a shared projection's concatenated weight shadow and bias vector
+ * (nn.MultiheadAttention.in_proj_weight / in_proj_bias slices of two modules, cross_modal_block_tacfn.py:98-117). */
+int hriemo_cast_copy_batch(const void* jobs_host, int njobs, hriemo_stream_t stream);
 int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed,
                         const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
 int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
