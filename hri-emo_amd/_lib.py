@@ -53,6 +53,8 @@ _SIGS = {
     "hriemo_cast_bf16_to_f32": ("pplp", "i"),
     "hriemo_cast_f32_to_bf16_batch": ("pip", "i"),
     "hriemo_cast_copy_batch": ("pip", "i"),
+    "hriemo_pack_rows": ("pppiiiipppp", "i"),
+    "hriemo_unpack_rows": ("pppiiippp", "i"),
     "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
     "hriemo_expand_rows": ("ppilp", "i"),
     "hriemo_rowdot_fwd": ("pppppiip", "i"),

@@ -1033,11 +1033,25 @@ def varlen():
 
 
 class Seq:
-    """packed rows of one modality: cu int32 [B+1] (device), idx int64 [N] packed row -> row of the padded [B*L] layout"""
-    __slots__ = ("cu", "idx", "B", "L", "Lmax", "N")
+    """packed rows of one modality: cu int32 [B+1] (device), idx int64 [N] packed row -> row of the padded [Breal*L] layout.
+    Bucketed form (seq_bucket, one captured graph for every batch): N = the bucket's row count, the rows beyond the last real
+    sequence form ONE extra sequence (B = Breal + 1, cu has B+1 entries) of zeros, so every kernel writes every row."""
+    __slots__ = ("cu", "idx", "B", "L", "Lmax", "N", "Breal")
 
-    def __init__(self, cu, idx, B, L, Lmax, N):
+    def __init__(self, cu, idx, B, L, Lmax, N, Breal=None):
         self.cu, self.idx, self.B, self.L, self.Lmax, self.N = cu, idx, B, L, Lmax, N
+        self.Breal = B if Breal is None else Breal
+
+
+def seq_bucket(cu, B, L, n_rows):
+    """Seq over `n_rows` packed rows whose lengths live in DEVICE memory: cu int32 [B+2] = [0, cumulative valid lengths of the B
+    sequences ..., n_rows] (the caller refreshes it per batch; cu[B] < n_rows, n_rows - cu[B] <= L).  Nothing here depends on
+    the lengths, so a step captured with it replays for every batch that fits the bucket."""
+    idx = torch.empty(n_rows, dtype=torch.int64, device=cu.device)      # written by the first pack of the step (hriemo_pack_rows)
+    return Seq(cu, idx, B + 1, L, L, n_rows, Breal=B)
+
+
+SEQ_OVERRIDE = None       # (Seq audio, Seq text) injected by dp.DataParallelStep for its bucketed packed graphs
 
 
 _SEQ_PLANS = {}
@@ -1069,8 +1083,65 @@ def seq_plan(mask, B, L):
     return plan
 
 
+class PackFn(torch.autograd.Function):
+    """(x16 [B, L, d], x32 | None) -> packed ([1, N, d], twin | None): ONE gather launch for the pair (hriemo_pack_rows), bucket
+    padding rows written as zeros; also fills seq.idx (padded row of every packed row)."""
+
+    @staticmethod
+    def forward(ctx, x16, x32, seq):
+        ctx.set_materialize_grads(False)
+        B, L, d = x16.shape
+        x16c = _contig_bf16(x16)
+        x32c = _c32(x32)
+        p16 = torch.empty((1, seq.N, d), dtype=BF16, device=x16.device)
+        p32 = torch.empty((1, seq.N, d), dtype=torch.float32, device=x16.device) if x32 is not None else None
+        _lib.call("hriemo_pack_rows", _p(x16c), _p(x32c), _p(seq.cu), seq.Breal, L, d, seq.N, _p(p16), _p(p32), _p(seq.idx), _stream())
+        ctx.seq, ctx.d, ctx.has32 = seq, d, x32 is not None
+        return p16, p32
+
+    @staticmethod
+    def backward(ctx, d16, d32):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) or (d16 is None and d32 is None):
+            return None, None, None
+        y16, y32 = _unpack_pair(d16, d32, ctx.seq, ctx.d)
+        return y16, (y32 if ctx.has32 else None), None
+
+
+def _unpack_pair(p16, p32, seq, d):
+    dev = (p16 if p16 is not None else p32).device
+    y16 = torch.empty((seq.Breal, seq.L, d), dtype=BF16, device=dev) if p16 is not None else None
+    y32 = torch.empty((seq.Breal, seq.L, d), dtype=torch.float32, device=dev) if p32 is not None else None
+    p16c = None if p16 is None else _contig_bf16(p16)
+    _lib.call("hriemo_unpack_rows", _p(p16c), _p(_c32(p32)), _p(seq.cu), seq.Breal, seq.L, d, _p(y16), _p(y32), _stream())
+    return y16, y32
+
+
+class UnpackFn(torch.autograd.Function):
+    """packed ([1, N, d], twin | None) -> padded ([B, L, d], twin | None) with zeros at the PAD positions: one scatter launch
+    (hriemo_unpack_rows); backward = the gather of the pair's gradients (bucket padding rows get zeros)."""
+
+    @staticmethod
+    def forward(ctx, p16, p32, seq):
+        ctx.set_materialize_grads(False)
+        d = p16.shape[-1]
+        ctx.seq, ctx.d = seq, d
+        return _unpack_pair(p16, p32, seq, d)
+
+    @staticmethod
+    def backward(ctx, d16, d32):
+        if d16 is None and d32 is None:
+            return None, None, None
+        seq, d = ctx.seq, ctx.d
+        dev = (d16 if d16 is not None else d32).device
+        g16 = torch.empty((1, seq.N, d), dtype=BF16, device=dev) if d16 is not None else None
+        g32 = torch.empty((1, seq.N, d), dtype=torch.float32, device=dev) if d32 is not None else None
+        d16c = None if d16 is None else _contig_bf16(d16)
+        _lib.call("hriemo_pack_rows", _p(d16c), _p(_c32(d32)), _p(seq.cu), seq.Breal, seq.L, d, seq.N, _p(g16), _p(g32), None, _stream())
+        return g16, g32, None
+
+
 def pack_rows(x, seq):
-    """[B, L, d] -> [1, N, d] (valid rows only); None stays None"""
+    """[B, L, d] -> [1, N, d] by torch indexing: what PackFn computes, stated on seq.idx (host-logic tests; the model calls pack_pair)"""
     if x is None:
         return None
     B, L, d = x.shape
@@ -1078,12 +1149,23 @@ def pack_rows(x, seq):
 
 
 def unpack_rows(x, seq):
-    """[1, N, d] -> [B, L, d] with zeros at the PAD positions"""
+    """[1, N, d] -> [B, L, d] with zeros at the PAD positions by torch indexing (see pack_rows)"""
     if x is None:
         return None
     d = x.shape[-1]
     out = torch.zeros((seq.B * seq.L, d), dtype=x.dtype, device=x.device)
     return out.index_copy(0, seq.idx, x.reshape(seq.N, d)).view(seq.B, seq.L, d)
+
+
+def pack_pair(x16, x32, seq):
+    """[B, L, d] pair -> packed [1, N, d] pair (valid rows only)"""
+    p16, p32 = PackFn.apply(x16, x32, seq)
+    return p16, p32
+
+
+def unpack_pair(p16, p32, seq):
+    """packed [1, N, d] pair -> [B, L, d] pair with zeros at the PAD positions"""
+    return UnpackFn.apply(p16, p32, seq)
 
 
 # ----------------------------------------------------------------------------- sub-layer Functions

@@ -998,6 +998,71 @@ extern "C" int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float 
   return 0;
 }
 
+// ---- packed (varlen) sequences: gather / scatter between the padded [B, L, d] layout and the packed [n_rows, d] one -----------
+// Sequence b owns packed rows cu[b] .. cu[b+1]-1 (its first cu[b+1]-cu[b] positions of the padded layout; the collate pads at the
+// end, train_fusion_seq_level_decoder.py:191-232).  The lengths are DEVICE data: a captured graph serves every batch whose packed
+// rows fit n_rows.  Packed rows cu[B] .. n_rows-1 belong to no sequence (the host rounds the row count up to a bucket and treats
+// them as one extra sequence): they are written as zeros, so every later kernel sees finite values there and their gradients are
+// exactly zero.  One launch moves the bf16 tensor and its fp32 twin (either may be NULL) and emits the padded row of every packed
+// row (row_index of hriemo_add_ln_*_rows: the dropout hash stays keyed by the padded position).  One wave per row.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4r;
+__device__ __forceinline__ void copy_row16(const char* src, char* dst, int bytes, int lane) {
+  for (int o = lane * 16; o < bytes; o += 64 * 16) *(u32x4r*)(dst + o) = src ? *(const u32x4r*)(src + o) : (u32x4r){0u, 0u, 0u, 0u};
+}
+__global__ __launch_bounds__(256) void pack_rows_kernel(const bf16_t* __restrict__ X16, const float* __restrict__ X32, const int* __restrict__ cu,
+                                                        int B, int L, int d, int n_rows, bf16_t* __restrict__ P16, float* __restrict__ P32,
+                                                        long long* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  int lo = 0, hi = B;                       // largest b in [0, B] with cu[b] <= r  (b == B: beyond the last sequence)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cu[mid] <= r) lo = mid; else hi = mid - 1;
+  }
+  const int b = lo, l = r - cu[b];
+  const bool real = b < B && l < L;
+  const long src = (long)b * L + l;
+  if (rows != nullptr && lane == 0) rows[r] = src;
+  if (P16 != nullptr) copy_row16(real ? (const char*)(X16 + src * d) : nullptr, (char*)(P16 + (long)r * d), d * 2, lane);
+  if (P32 != nullptr) copy_row16(real ? (const char*)(X32 + src * d) : nullptr, (char*)(P32 + (long)r * d), d * 4, lane);
+}
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const bf16_t* __restrict__ P16, const float* __restrict__ P32, const int* __restrict__ cu,
+                                                          int B, int L, int d, bf16_t* __restrict__ Y16, float* __restrict__ Y32) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * L) return;
+  const int b = (int)(row / L), l = (int)(row - (long)b * L);
+  const int c0 = cu[b], len = cu[b + 1] - c0;
+  const bool real = l < len;
+  const long src = (long)c0 + l;
+  if (Y16 != nullptr) copy_row16(real ? (const char*)(P16 + src * d) : nullptr, (char*)(Y16 + row * d), d * 2, lane);
+  if (Y32 != nullptr) copy_row16(real ? (const char*)(P32 + src * d) : nullptr, (char*)(Y32 + row * d), d * 4, lane);
+}
+extern "C" int hriemo_pack_rows(const void* X16, const float* X32, const int* cu_seqlens, int B, int L, int d, int n_rows, void* P16,
+                                float* P32, long long* row_index, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && L > 0 && d > 0 && d % 8 == 0 && n_rows > 0 && cu_seqlens != nullptr, "pack_rows: bad shape (B=%d L=%d d=%d n_rows=%d)", B, L, d, n_rows);
+  HRIEMO_CHECK((X16 == nullptr) == (P16 == nullptr) && (X32 == nullptr) == (P32 == nullptr), "pack_rows: source and destination of a tensor must both be given or both be NULL");
+  HRIEMO_CHECK(((uintptr_t)X16 % 16) == 0 && ((uintptr_t)X32 % 16) == 0 && ((uintptr_t)P16 % 16) == 0 && ((uintptr_t)P32 % 16) == 0, "pack_rows: unaligned operand");
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, st, (const bf16_t*)X16, X32, cu_seqlens, B, L, d, n_rows, (bf16_t*)P16, P32, row_index);
+  HRIEMO_LAUNCH_CHECK("pack_rows_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (double)n_rows * d * ((X16 ? 4.0 : 0.0) + (X32 ? 8.0 : 0.0)));
+  return 0;
+}
+extern "C" int hriemo_unpack_rows(const void* P16, const float* P32, const int* cu_seqlens, int B, int L, int d, void* Y16, float* Y32,
+                                  hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && L > 0 && d > 0 && d % 8 == 0 && cu_seqlens != nullptr, "unpack_rows: bad shape (B=%d L=%d d=%d)", B, L, d);
+  HRIEMO_CHECK((P16 == nullptr) == (Y16 == nullptr) && (P32 == nullptr) == (Y32 == nullptr), "unpack_rows: source and destination of a tensor must both be given or both be NULL");
+  HRIEMO_CHECK(((uintptr_t)P16 % 16) == 0 && ((uintptr_t)P32 % 16) == 0 && ((uintptr_t)Y16 % 16) == 0 && ((uintptr_t)Y32 % 16) == 0, "unpack_rows: unaligned operand");
+  const long rows = (long)B * L;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)P16, P32, cu_seqlens, B, L, d, (bf16_t*)Y16, Y32);
+  HRIEMO_LAUNCH_CHECK("unpack_rows_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (double)rows * d * ((P16 ? 4.0 : 0.0) + (P32 ? 8.0 : 0.0)));
+  return 0;
+}
+
 extern "C" int hriemo_expand_rows(const float* q, void* out, int B, long n, hipStream_t st) {
   HRIEMO_CHECK(B > 0 && n > 0, "expand: empty");
   long g = ((long)B * n + 255) / 256;

@@ -18,6 +18,9 @@ import torch.distributed as dist
 # gradient memset on the side stream beside the first kernels of the forward instead of in front of them: measured neutral
 # (8.18 vs 8.14-8.19 ms per step on one box), opt-in
 _ZERO_BESIDE = os.environ.get("HRIEMO_ZERO_BESIDE", "0") == "1"
+# packed (varlen) graphs: the packed row count of a modality is rounded up to a multiple of (padded rows / this): finer = fewer
+# wasted rows, more distinct graphs over a run (DataParallelStep.capture)
+_VARLEN_BUCKETS = max(1, int(os.environ.get("HRIEMO_VARLEN_BUCKETS", "64")))
 
 
 class GradBuckets:
@@ -235,6 +238,8 @@ class DataParallelStep:
         self._graph = None
         self._static = None
         self._static_loss = None
+        self._pb = None               # packed (varlen) bucket graphs: {(rows audio, rows text): record}, see capture()
+        self._pool = None
 
     def set_global_batch(self, global_batch):
         lo, hi = shard_bounds(global_batch, self.rank, self.world)
@@ -269,14 +274,21 @@ class DataParallelStep:
         self.buckets.finish()
         return total
 
-    def capture(self, h_a, h_t, m_a, m_t, y, collectives=False):
+    def capture(self, h_a, h_t, m_a, m_t, y, collectives=False, lengths=None):
         """Record one step on static copies of the batch tensors; later ``step()`` calls replay it.
 
         collectives=True: the gradient exchange is captured INSIDE the graph -- every bucket's all-reduce is launched from its
         gradient-ready hook while backward is being recorded (on the capture's origin stream; the process group forks its
         communication stream from there), the waits and the 1/N average close the graph -- so a replay overlaps the exchange
         with backward exactly like the eager mode does, without the host enqueueing ~450 launches per step.  Needs a backend
-        whose collectives can be stream-captured (RCCL can); the hooks must be installed (overlap=True) and not suspended."""
+        whose collectives can be stream-captured (RCCL can); the hooks must be installed (overlap=True) and not suspended.
+
+        Packed (varlen) mode (``hri_emo_amd.set_varlen(True)`` and both padding masks given): the sequence lengths are DEVICE
+        data of the captured step (cu_seqlens buffers refreshed before every replay), only the packed row counts are baked in,
+        rounded up to a bucket (1/64 of the padded rows; the surplus rows form one extra all-zero sequence).  ``step()`` then
+        serves EVERY batch of these shapes: a batch whose row counts fall into a bucket not seen yet captures that bucket's
+        graph on the spot (same static inputs, one memory pool).  ``lengths`` = (audio lengths, text lengths) as host lists /
+        CPU tensors spares the device -> host read of the masks' row sums (one sync per step otherwise)."""
         from . import _ops
         if collectives and not self.buckets._hooks:
             raise RuntimeError("capture(collectives=True) needs the gradient-ready hooks: GradBuckets(overlap=True) at world size > 1 "
@@ -287,7 +299,77 @@ class DataParallelStep:
         if collectives:
             self.buckets.suspended = False
         self._static = [None if t is None else t.clone() for t in (h_a, h_t, m_a, m_t, y)]
-        self.release_graph()              # a re-capture replaces the old graph: its pinned buffers go first
+        self.release_graph()              # a re-capture replaces the old graph(s): their pinned buffers go first
+        self._collectives = bool(collectives)
+        if _ops.varlen() and m_a is not None and m_t is not None and _ops.precision() == "bf16":
+            if collectives and self.world > 1:
+                raise RuntimeError("capture(collectives=True) in packed (varlen) mode: ranks meet new buckets at different steps and a "
+                                   "bucket's capture runs eager warm-up exchanges -- capture without collectives (exchange after the "
+                                   "replay) or run the padded path")
+            dev = self._static[0].device
+            B, La, Lt = h_a.shape[0], h_a.shape[1], h_t.shape[1]
+            self._pb = {"graphs": {}, "B": B, "La": La, "Lt": Lt,
+                        "cu_a": torch.zeros(B + 2, dtype=torch.int32, device=dev), "cu_t": torch.zeros(B + 2, dtype=torch.int32, device=dev)}
+            key = self._packed_key(m_a, m_t, lengths)
+            rec = self._packed_graph(key)
+            self._graph, self._static_loss, self._keep = rec["graph"], rec["loss"], []
+        else:
+            self._graph, self._static_loss, self._keep = self._capture_graph(None)
+        self._packed = self._pb is not None
+        self._mask_seen = {}
+        self._replay = True
+        self._exchange_in_graph = bool(collectives)
+        if collectives:
+            self.buckets.suspended = True         # from now on hooks fire only inside replays (they are baked into the graph)
+
+    # ---- packed (varlen) bucket graphs
+    def _packed_key(self, m_a, m_t, lengths):
+        """host-side: the batch's cu_seqlens written to the static device buffers + the bucket (rows audio, rows text) it needs"""
+        pb = self._pb
+        B, La, Lt = pb["B"], pb["La"], pb["Lt"]
+        if lengths is None:
+            # one device -> host read per step; masks must be prefix masks with no empty sequence (the collate's form)
+            va, vt = ~m_a.bool(), ~m_t.bool()
+            la, lt = va.sum(1), vt.sum(1)
+            ok = ((va == (torch.arange(La, device=m_a.device)[None, :] < la[:, None])).all()
+                  & (vt == (torch.arange(Lt, device=m_t.device)[None, :] < lt[:, None])).all() & (la > 0).all() & (lt > 0).all())
+            host = torch.cat([la, lt, ok.long().view(1)]).tolist()
+            if not host[-1]:
+                raise RuntimeError("DataParallelStep (packed mode): padding masks must mark a suffix of every row and leave at least "
+                                   "one valid position -- use_graph(False) runs such a batch on the padded path")
+            la, lt = host[:B], host[B:2 * B]
+        else:
+            la, lt = [int(x) for x in lengths[0]], [int(x) for x in lengths[1]]
+            if len(la) != B or len(lt) != B or min(la) < 1 or min(lt) < 1 or max(la) > La or max(lt) > Lt:
+                raise ValueError("DataParallelStep (packed mode): lengths must hold one value in [1, L] per utterance and modality")
+        out = []
+        for lens, L, buf in ((la, La, pb["cu_a"]), (lt, Lt, pb["cu_t"])):
+            g = max(8, (B * L) // _VARLEN_BUCKETS // 8 * 8)
+            g = min(g, L)                         # the surplus rows are ONE sequence of at most L rows
+            n = sum(lens)
+            rows = (n // g + 1) * g               # > n: the extra sequence is never empty
+            cu = [0]
+            for x in lens:
+                cu.append(cu[-1] + x)
+            cu.append(rows)
+            buf.copy_(torch.tensor(cu, dtype=torch.int32))
+            out.append(rows)
+        return tuple(out)
+
+    def _packed_graph(self, key):
+        from . import _ops
+        pb = self._pb
+        rec = pb["graphs"].get(key)
+        if rec is None:
+            seqs = (_ops.seq_bucket(pb["cu_a"], pb["B"], pb["La"], key[0]), _ops.seq_bucket(pb["cu_t"], pb["B"], pb["Lt"], key[1]))
+            graph, loss, keep = self._capture_graph(seqs)
+            rec = pb["graphs"][key] = {"graph": graph, "loss": loss, "keep": keep, "seqs": seqs}
+        return rec
+
+    def _capture_graph(self, seqs):
+        """warm-up + capture of one step on self._static; seqs = the packed plans of a bucket graph (or None) -> (graph, loss, keep)"""
+        from . import _ops
+        collectives = self._collectives
         # ONE capture stream per device for every capture of the process: workspaces are keyed by stream, a fresh stream per
         # capture would allocate (and, with a graph alive, retire instead of free) a fresh 64 MB+ set each time
         dev = self._static[0].device
@@ -295,50 +377,53 @@ class DataParallelStep:
         if side is None:
             side = DataParallelStep._capture_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture wants
-            for _ in range(2):
-                self._fwd_bwd(*self._static)
-                if collectives:
-                    self.buckets.finish()         # the warm-up steps exchange eagerly (every rank alike) and leave the buckets reset
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        _ops.CAPTURING = True
-        _ops.CAPTURE_ORIGIN = side        # every helper-stream fork of the step must start here (_ops.fork refuses nested forks)
-        _ops.begin_step()
+        _ops.SEQ_OVERRIDE = seqs
         try:
-            # capture on the stream the warm-up ran on: its workspaces (keyed by stream) exist already, so nothing the
-            # graph points into comes from the graph's private pool or is first sized during capture.
-            # thread_local: the RCCL watchdog thread may query events while we capture
-            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                _ops.bump_seed_word(self._static[0].device)
-                self._static_loss = self._fwd_bwd(*self._static)
-                if collectives:
-                    self.buckets.finish()         # waits on the captured collectives + the average: part of the graph
+            with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture wants
+                for _ in range(2):
+                    self._fwd_bwd(*self._static)
+                    if collectives:
+                        self.buckets.finish()         # the warm-up steps exchange eagerly (every rank alike) and leave the buckets reset
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            if seqs is not None and self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()       # the bucket graphs never run concurrently: one pool for all
+            _ops.CAPTURING = True
+            _ops.CAPTURE_ORIGIN = side        # every helper-stream fork of the step must start here (_ops.fork refuses nested forks)
+            _ops.begin_step()
+            try:
+                # capture on the stream the warm-up ran on: its workspaces (keyed by stream) exist already, so nothing the
+                # graph points into comes from the graph's private pool or is first sized during capture.
+                # thread_local: the RCCL watchdog thread may query events while we capture
+                kw = {"pool": self._pool} if seqs is not None else {}
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local", **kw):
+                    _ops.bump_seed_word(self._static[0].device)
+                    loss = self._fwd_bwd(*self._static)
+                    if collectives:
+                        self.buckets.finish()         # waits on the captured collectives + the average: part of the graph
+            finally:
+                _ops.CAPTURING = False
+                _ops.CAPTURE_ORIGIN = None
         finally:
-            _ops.CAPTURING = False
-            _ops.CAPTURE_ORIGIN = None
+            _ops.SEQ_OVERRIDE = None
         _ops.GRAPHS_ALIVE += 1            # from now on outgrown workspaces are retired, not freed (_ops.workspace)
         # buffers the captured kernels point into (column-sum partials, queued weight-gradient operands) live exactly as long as
         # this graph: they move from the process-wide lists to the graph's owner
-        self._keep = _ops._deferred.keep + _ops._small_dw.keep
+        keep = _ops._deferred.keep + _ops._small_dw.keep
         _ops._deferred.keep, _ops._small_dw.keep = [], []
-        self._packed = _ops.varlen()      # the graph bakes the sequence lengths of THIS batch in (packed rows, cu_seqlens)
-        self._mask_seen = {}              # k -> (data_ptr, _version) of the caller's mask tensor last compared with the captured one
-        self._graph = graph
-        self._replay = True
-        self._exchange_in_graph = bool(collectives)
-        if collectives:
-            self.buckets.suspended = True         # from now on hooks fire only inside replays (they are baked into the graph)
+        return graph, loss, keep
 
     def release_graph(self):
         """drop the captured step (before a re-capture, or to free its buffers): the graph, the buffers its kernels point into"""
         from . import _ops
         if self._graph is not None:
             torch.cuda.synchronize()
+            n = len(self._pb["graphs"]) if self._pb is not None else 1
             self._graph = None
             self._keep = []
-            _ops.GRAPHS_ALIVE = max(0, _ops.GRAPHS_ALIVE - 1)
+            self._pb = None
+            _ops.GRAPHS_ALIVE = max(0, _ops.GRAPHS_ALIVE - n)
             if _ops.GRAPHS_ALIVE == 0:
                 del _ops._ws_retired[:]   # no graph points into the outgrown workspaces any more
 
@@ -348,26 +433,34 @@ class DataParallelStep:
         self._replay = bool(on) and self._graph is not None
         self.buckets.suspended = self._replay     # eager steps: the hooks drive the exchange; replays: it follows / is inside the graph
 
-    def step(self, h_a, h_t, m_a, m_t, y):
+    def step(self, h_a, h_t, m_a, m_t, y, lengths=None):
         if self._graph is not None and getattr(self, "_replay", True):
-            for k, (s, t) in enumerate(zip(self._static, (h_a, h_t, m_a, m_t, y))):
-                if s is not None and t is not None and s.data_ptr() != t.data_ptr():
-                    if getattr(self, "_packed", False) and k in (2, 3):
-                        # the comparison is a host-device sync: once per distinct caller tensor (address + version), not per step
-                        seen = (t.data_ptr(), t._version)
-                        if self._mask_seen.get(k) == seen:
-                            continue
-                        if not torch.equal(s, t.to(s.dtype)):
-                            raise RuntimeError("DataParallelStep: this step was captured with packed (varlen) sequences; its graph can "
-                                               "only be replayed with the padding masks it was captured with -- use_graph(False) or "
-                                               "capture per length pattern")
-                        self._mask_seen[k] = seen
-                        continue
-                    s.copy_(t)
-            self._graph.replay()
+            graph, loss = self._graph, self._static_loss
+            if self._pb is not None:
+                # packed mode: any padding masks of the captured shapes; the lengths travel as device data (cu_seqlens), the row
+                # counts pick the bucket graph (captured now if this bucket was not seen before)
+                if m_a is None or m_t is None:
+                    raise RuntimeError("DataParallelStep (packed mode): both padding masks are needed")
+                seen = (m_a.data_ptr(), m_a._version, m_t.data_ptr(), m_t._version)
+                if lengths is None and self._mask_seen.get("key") == seen:
+                    key = self._mask_seen["val"]          # the same mask tensors as last step: no second device -> host read
+                    self._pb["cu_a"].copy_(self._mask_seen["cu"][0]); self._pb["cu_t"].copy_(self._mask_seen["cu"][1])
+                else:
+                    key = self._packed_key(m_a, m_t, lengths)
+                    self._mask_seen = {"key": seen, "val": key, "cu": (self._pb["cu_a"].clone(), self._pb["cu_t"].clone())}
+                for s, t in zip(self._static, (h_a, h_t, m_a, m_t, y)):
+                    if s is not None and t is not None and s.data_ptr() != t.data_ptr():
+                        s.copy_(t)
+                rec = self._packed_graph(key)             # captures on self._static (already this batch) if the bucket is new
+                graph, loss = rec["graph"], rec["loss"]
+            else:
+                for s, t in zip(self._static, (h_a, h_t, m_a, m_t, y)):
+                    if s is not None and t is not None and s.data_ptr() != t.data_ptr():
+                        s.copy_(t)
+            graph.replay()
             if not self._exchange_in_graph:
                 self.buckets.finish()
-            return self._static_loss
+            return loss
         loss = self._fwd_bwd(h_a, h_t, m_a, m_t, y)
         self.buckets.finish()
         return loss

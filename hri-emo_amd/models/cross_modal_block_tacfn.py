@@ -90,7 +90,7 @@ class CrossModalBlock(nn.Module):
         side_hook: called ON the side stream once the text branch's self-attention stage is enqueued -- where that stream waits
         for the audio branch anyway (FusionWithEmotionDecoder runs the decoder's encoder-independent prologue there); only the
         two-stream paths call it.
-        plan = (Seq audio, Seq text): a / t hold the packed valid rows ([1, N, d], _ops.pack_rows) and the attention kernels get
+        plan = (Seq audio, Seq text): a / t hold the packed valid rows ([1, N, d], _ops.pack_pair) and the attention kernels get
         cu_seqlens instead of padding masks."""
         B, La, _ = a.shape
         Lt = t.shape[1]
@@ -256,12 +256,15 @@ class CrossModalTransformer(nn.Module):
         _ops.FLUSH_SITES.add(self.layers[0]._site[1])        # layer-0 text self-attention: the last text-branch backward (_ops._DeferredWgrad)
         if _ops.varlen() and not need and mask_a is not None and mask_t is not None and _ops.precision() == "bf16":
             # the encoder on the valid rows only (prefix masks, as the collate builds them); anything else
-            # takes the padded path
-            sa = _ops.seq_plan(mask_a, a.shape[0], a.shape[1])
-            st = _ops.seq_plan(mask_t, t.shape[0], t.shape[1])
+            # takes the padded path.  dp.DataParallelStep injects bucketed plans whose lengths are device data (_ops.SEQ_OVERRIDE).
+            if _ops.SEQ_OVERRIDE is not None:
+                sa, st = _ops.SEQ_OVERRIDE
+            else:
+                sa = _ops.seq_plan(mask_a, a.shape[0], a.shape[1])
+                st = _ops.seq_plan(mask_t, t.shape[0], t.shape[1])
             if sa is not None and st is not None:
                 plan = (sa, st)
-                a, a32, t, t32 = _ops.pack_rows(a, sa), _ops.pack_rows(a32, sa), _ops.pack_rows(t, st), _ops.pack_rows(t32, st)
+                (a, a32), (t, t32) = _ops.pack_pair(a, a32, sa), _ops.pack_pair(t, t32, st)
         for i, layer in enumerate(self.layers):
             a, a32, t, t32, maps = layer._fwd_pair(a, a32, t, t32, mask_a, mask_t, need, plan, side_hook if i == 0 else None)
             if need:
@@ -269,8 +272,7 @@ class CrossModalTransformer(nn.Module):
             if i == 0 and after_first_layer is not None:
                 after_first_layer()
         if plan is not None:
-            a, a32 = _ops.unpack_rows(a, plan[0]), _ops.unpack_rows(a32, plan[0])
-            t, t32 = _ops.unpack_rows(t, plan[1]), _ops.unpack_rows(t32, plan[1])
+            (a, a32), (t, t32) = _ops.unpack_pair(a, a32, plan[0]), _ops.unpack_pair(t, t32, plan[1])
         return a, a32, t, t32, all_layers_attn
 
     def forward(self, h_a, h_t, mask_a=None, mask_t=None, return_attention=False):

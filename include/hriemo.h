@@ -173,6 +173,16 @@ int hriemo_add_ln_bwd_rows(const void* dY, const void* G, const void* X, const f
                            const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,
                            int M, int d, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
                            unsigned site, long row_offset, float* workspace, const long long* row_index, hriemo_stream_t stream);
+/* Packed (varlen) sequences <-> padded layout, lengths read from DEVICE memory (one captured graph serves every batch whose valid
+ * rows fit n_rows; replaces the reference's pad-to-the-batch-maximum, train_fusion_seq_level_decoder.py:191-232).  cu_seqlens:
+ * int32 [B+1], sequence b = packed rows cu[b]..cu[b+1]-1 = its first positions of the padded [B, L, d] layout.  pack: packed rows
+ * cu[B]..n_rows-1 (bucket padding) are written as zeros; row_index[r] (int64 [n_rows], may be NULL) = padded row of packed row r
+ * (the row key of hriemo_add_ln_*_rows).  unpack: PAD positions are written as zeros.  X16/P16 (bf16) and X32/P32 (fp32 twin):
+ * either pair may be NULL. */
+int hriemo_pack_rows(const void* X16, const float* X32, const int* cu_seqlens, int B, int L, int d, int n_rows, void* P16, float* P32,
+                     long long* row_index, hriemo_stream_t stream);
+int hriemo_unpack_rows(const void* P16, const float* P32, const int* cu_seqlens, int B, int L, int d, void* Y16, float* Y32,
+                       hriemo_stream_t stream);
 long hriemo_add_ln_bwd_workspace_bytes(int M, int d);
 int hriemo_add_ln_bwd(const void* dY, const void* G, const void* X, const float* X32, const float* gamma, const float* mean,
                       const float* rstd, void* dX, void* dG, float* dgamma, float* dbeta, float* dbias, int accumulate,

@@ -205,24 +205,114 @@ def test_train_step_with_dropout_packed_equals_padded(H):
     assert abs(l2 - l1) > 1e-6                     # and another seed is another draw (the dropout is really on)
 
 
-def test_captured_step_refuses_other_masks_in_packed_mode(H):
+def test_pack_unpack_rows_kernels_with_device_side_lengths(H):
+    """hriemo_pack_rows / hriemo_unpack_rows through the C-ABI: the lengths are read from device memory (cu_seqlens), bucket
+    padding rows come out as zeros, row_index is the padded row of every packed row, unpack zero-fills the PAD positions; the
+    bf16 tensor and its fp32 twin travel in one launch"""
+    from hri_emo_amd import _lib, _ops
+    g = torch.Generator().manual_seed(5)
+    B, L, d, n_rows = 5, 37, 72, 160
+    lens = torch.tensor([37, 1, 20, 33, 9])
+    cu_ = torch.zeros(B + 2, dtype=torch.int32)
+    cu_[1:B + 1] = torch.cumsum(lens, 0)
+    cu_[B + 1] = n_rows
+    cu_ = cu_.cuda()
+    x32 = torch.randn(B, L, d, generator=g).cuda()
+    x16 = x32.bfloat16()
+    N = int(lens.sum())
+    idx = torch.cat([b * L + torch.arange(int(lens[b])) for b in range(B)]).cuda()
+    st = _ops._stream()
+    for with16, with32 in ((True, True), (True, False), (False, True)):
+        p16 = torch.full((n_rows, d), 7.0, dtype=torch.bfloat16, device="cuda") if with16 else None
+        p32 = torch.full((n_rows, d), 7.0, device="cuda") if with32 else None
+        rows = torch.full((n_rows,), -1, dtype=torch.int64, device="cuda")
+        _lib.call("hriemo_pack_rows", _ops._p(x16 if with16 else None), _ops._p(x32 if with32 else None), _ops._p(cu_), B, L, d, n_rows,
+                  _ops._p(p16), _ops._p(p32), _ops._p(rows), st)
+        assert torch.equal(rows[:N], idx) and torch.equal(rows[N:], B * L + torch.arange(n_rows - N, device="cuda"))
+        if with16:
+            assert torch.equal(p16[:N], x16.view(B * L, d)[idx]) and float(p16[N:].float().abs().sum()) == 0.0
+        if with32:
+            assert torch.equal(p32[:N], x32.view(B * L, d)[idx]) and float(p32[N:].abs().sum()) == 0.0
+        y16 = torch.full((B, L, d), 3.0, dtype=torch.bfloat16, device="cuda") if with16 else None
+        y32 = torch.full((B, L, d), 3.0, device="cuda") if with32 else None
+        _lib.call("hriemo_unpack_rows", _ops._p(p16), _ops._p(p32), _ops._p(cu_), B, L, d, _ops._p(y16), _ops._p(y32), st)
+        valid = (torch.arange(L)[None] < lens[:, None]).cuda()
+        if with16:
+            assert torch.equal(y16[valid], x16[valid]) and float(y16[~valid].float().abs().sum()) == 0.0
+        if with32:
+            assert torch.equal(y32[valid], x32[valid]) and float(y32[~valid].abs().sum()) == 0.0
+
+
+def _ragged_batch(B, Ta, Tt, d, ne, seed, lo_a, lo_t):
+    g = torch.Generator().manual_seed(seed)
+    h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda(), torch.randn(B, Tt, d, generator=g).cuda()
+    la = torch.randint(lo_a, Ta + 1, (B,), generator=g); lt = torch.randint(lo_t, Tt + 1, (B,), generator=g)
+    m_a, m_t = (torch.arange(Ta)[None] >= la[:, None]).cuda(), (torch.arange(Tt)[None] >= lt[:, None]).cuda()
+    y = (torch.rand(B, ne, generator=g) < 0.3).float().cuda()
+    return (h_a, h_t, m_a, m_t, y), (la.tolist(), lt.tolist())
+
+
+def test_captured_packed_step_serves_every_batch(H):
+    """One capture in packed mode, then batches with OTHER padding masks: the lengths are device data of the graph (cu_seqlens),
+    the packed row count is rounded up to a bucket whose surplus rows form an all-zero extra sequence.  Every replay must give
+    the loss and the parameter gradients of the padded eager step on the same batch (dropout 0) -- for a batch in the captured
+    bucket, for batches that open new buckets (captured on the spot), with the lengths read from the masks or handed over."""
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=256, num_emotions=5, n_heads=8, dropout=0.0).cuda().train()
+    B, Ta, Tt, d = 6, 150, 60, 256
+    dp = DataParallelStep(m, fusion_step_loss, overlap=False)
+    dp.set_global_batch(B)
+    batches = [_ragged_batch(B, Ta, Tt, d, 5, s, lo_a, lo_t) for s, lo_a, lo_t in ((4, 40, 10), (5, 40, 10), (6, 120, 50), (7, 1, 1), (8, 150, 60))]
+    ref = []
+    H.set_varlen(False)
+    for batch, _ in batches:                      # the padded eager step is the yardstick
+        loss = float(dp.step(*batch))
+        ref.append((loss, dp.buckets.flat.clone()))
+    H.set_varlen(True)
+    dp.capture(*batches[0][0])
+    seen = set()
+    for i, (batch, lens) in enumerate(batches):
+        loss = float(dp.step(*batch, lengths=lens if i % 2 else None))
+        torch.cuda.synchronize()
+        seen.add(tuple(int(x) for x in (dp._pb["cu_a"][-1], dp._pb["cu_t"][-1])))
+        assert abs(loss - ref[i][0]) <= 1e-5 * max(1.0, abs(ref[i][0])), (i, loss, ref[i][0])
+        rel = float((dp.buckets.flat - ref[i][1]).norm() / ref[i][1].norm())
+        assert rel <= 1e-5, (i, rel)
+    assert len(dp._pb["graphs"]) == len(seen) >= 3            # full-length and very short batches fall into other buckets
+    loss = float(dp.step(*batches[1][0]))                         # back to a bucket that exists: a replay, same numbers
+    assert abs(loss - ref[1][0]) <= 1e-5 * max(1.0, abs(ref[1][0]))
+    with pytest.raises(RuntimeError, match="suffix"):
+        bad = batches[1][0][2].clone(); bad[0, 3] = True; bad[0, 4] = False
+        dp.step(batches[1][0][0], batches[1][0][1], bad, batches[1][0][3], batches[1][0][4])
+    dp.release_graph()
+
+
+def test_captured_packed_step_with_dropout_is_deterministic_per_seed(H):
+    """dropout on, packed bucket graph: replays from the same seed word are bit-identical (bucket padding rows carry zeros and
+    zero gradients, so nothing of them leaks into a sum), another seed gives another loss"""
+    from hri_emo_amd import _ops
     from hri_emo_amd.dp import DataParallelStep
     from hri_emo_amd.train import fusion_step_loss
     torch.manual_seed(3)
     m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.1).cuda().train()
-    g = torch.Generator().manual_seed(4)
     B, Ta, Tt, d = 4, 64, 32, 128
-    h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda().bfloat16(), torch.randn(B, Tt, d, generator=g).cuda().bfloat16()
-    m_a = (torch.arange(Ta)[None] >= torch.tensor([64, 30, 50, 10])[:, None]).cuda()
-    m_t = (torch.arange(Tt)[None] >= torch.tensor([32, 8, 20, 5])[:, None]).cuda()
-    y = (torch.rand(B, 4, generator=g) < 0.3).float().cuda()
+    (h_a, h_t, m_a, m_t, y), _ = _ragged_batch(B, Ta, Tt, d, 4, 9, 10, 5)
+    h_a, h_t = h_a.bfloat16(), h_t.bfloat16()
     H.set_varlen(True)
     dp = DataParallelStep(m, fusion_step_loss, overlap=False)
     dp.set_global_batch(B)
-    eager = float(dp.step(h_a, h_t, m_a, m_t, y))
+    dp.step(h_a, h_t, m_a, m_t, y)
     dp.capture(h_a, h_t, m_a, m_t, y)
-    l1 = float(dp.step(h_a, h_t, m_a.clone(), m_t.clone(), y))          # same masks in other tensors: fine
-    assert math.isfinite(l1) and abs(l1 - eager) < 0.5
-    other = m_a.clone(); other[1, 30:40] = False
-    with pytest.raises(RuntimeError, match="packed"):
-        dp.step(h_a, h_t, other, m_t, y)
+    sw = _ops.seed_word(h_a.device)
+    outs = []
+    for seed in (123, 123, 124):
+        sw.fill_(seed)
+        loss = dp.step(h_a, h_t, m_a, m_t, y)
+        torch.cuda.synchronize()
+        outs.append((float(loss), dp.buckets.flat.clone()))
+    assert math.isfinite(outs[0][0]) and bool(torch.isfinite(outs[0][1]).all())
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+    assert outs[2][0] != outs[0][0]
+    dp.release_graph()
