@@ -301,6 +301,27 @@ def main():
                 ragged["packed_ms_per_step"] = round(pms, 3)
                 ragged["packed_value"] = round(B / (pms * 1e-3), 1)
                 log(f"ragged masks, packed (varlen) encoder: {pms:.3f} ms/step")
+                # the same capture fed a DIFFERENT length pattern every step (lengths handed over as host lists, as a collate
+                # would): the lengths are device data of the graph, the packed row counts pick a bucket graph (captured on first
+                # sight, outside the timed loop)
+                fresh = []
+                for j in range(8):
+                    la_j = torch.randint(T_A // 2, T_A + 1, (B,), generator=g)
+                    lt_j = torch.randint(T_T // 2, T_T + 1, (B,), generator=g)
+                    fresh.append(((batch[0], batch[1], (torch.arange(T_A)[None] >= la_j[:, None]).to(device),
+                                   (torch.arange(T_T)[None] >= lt_j[:, None]).to(device), batch[4]), (la_j.tolist(), lt_j.tolist())))
+                for fb, fl in fresh:
+                    dp.step(*fb, lengths=fl)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    for fb, fl in fresh:
+                        dp.step(*fb, lengths=fl)
+                torch.cuda.synchronize()
+                fms = (time.perf_counter() - t1) / 16 * 1e3
+                ragged["packed_fresh_masks_ms_per_step"] = round(fms, 3)
+                ragged["packed_bucket_graphs"] = len(dp._pb["graphs"])
+                log(f"packed encoder, new masks every step: {fms:.3f} ms/step over {len(dp._pb['graphs'])} bucket graphs")
             finally:
                 _H.set_varlen(False)
             dp.capture(*batch)
