@@ -81,11 +81,14 @@ class DevicePrefetcher:
 
     ``convert`` maps the loader's item to a tuple of tensors (None entries pass through); ``dtypes`` optionally casts on the
     host before the copy (bf16 features halve the PCIe bytes).  On a CPU ``device`` the batches pass through unchanged
-    (tests, gloo rehearsals)."""
+    (tests, gloo rehearsals).  ``mask_slots=(i, j)``: the tuple entries that are the audio / text padding masks -- the batch is
+    handed out with one more element, ``(audio lengths, text lengths)`` as Python lists counted on the HOST copy of the masks, which
+    is what ``DataParallelStep.step(..., lengths=)`` wants in packed (varlen) mode instead of reading the masks back from the
+    device."""
 
-    def __init__(self, loader, device, depth=2, convert=None, dtypes=None):
+    def __init__(self, loader, device, depth=2, convert=None, dtypes=None, mask_slots=None):
         self.loader, self.device, self.depth = loader, torch.device(device), max(2, int(depth))
-        self.convert, self.dtypes = convert, dtypes
+        self.convert, self.dtypes, self.mask_slots = convert, dtypes, mask_slots
         self.cuda = self.device.type == "cuda"
         self._ring = [None] * self.depth          # slot -> {"host": [...], "dev": [...], "copied": event, "released": event}
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
@@ -97,8 +100,11 @@ class DevicePrefetcher:
         tensors = self.convert(item) if self.convert is not None else tuple(item)
         if self.dtypes is not None:
             tensors = tuple(t if (t is None or dt is None) else t.to(dt) for t, dt in zip(tensors, self.dtypes))
+        extra = ()
+        if self.mask_slots is not None:
+            extra = (tuple((~tensors[i].bool()).sum(1).tolist() for i in self.mask_slots),)
         if not self.cuda:
-            return tensors, None
+            return tensors + extra, None
         ent = self._ring[slot]
         shapes = [None if t is None else (tuple(t.shape), t.dtype) for t in tensors]
         if ent is None or ent["shapes"] != shapes:
@@ -122,7 +128,7 @@ class DevicePrefetcher:
                 if h is not None:
                     d_.copy_(h, non_blocking=True)
             ent["copied"].record(self._copy_stream)
-        return tuple(ent["dev"]), ent
+        return tuple(ent["dev"]) + extra, ent
 
     def __iter__(self):
         it = iter(self.loader)
