@@ -56,7 +56,8 @@ _SIGS = {
     "hriemo_pack_rows": ("pppiiiipppp", "i"),
     "hriemo_unpack_rows": ("pppiiippp", "i"),
     "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
-    "hriemo_expand_rows": ("ppilp", "i"),
+    "hriemo_expand_rows": ("pppilp", "i"),
+    "hriemo_seed_bump": ("pp", "i"),
     "hriemo_rowdot_fwd": ("pppppiip", "i"),
     "hriemo_rowdot_bwd": ("pppppppiiip", "i"),
     "hriemo_pool_chunks": ("i", "i"),

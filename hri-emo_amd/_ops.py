@@ -179,8 +179,25 @@ def seed_word(device):
     return t
 
 
+_ones = {}
+
+
+def one(device):
+    """the constant 1.0 a training loop may hand to ``loss.backward(gradient=...)``: the fused losses recognise this very tensor
+    and skip the multiplication by the incoming gradient (two elementwise launches and a fill on the step's serial chain)"""
+    t = _ones.get(device.index)
+    if t is None:
+        t = _ones[device.index] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def _is_one(g):
+    t = _ones.get(g.device.index) if g.is_cuda else None
+    return t is not None and g.data_ptr() == t.data_ptr() and g.dim() == 0
+
+
 def bump_seed_word(device):
-    seed_word(device).add_(0x9E3779B97F4A7C15 - (1 << 64))      # golden-ratio increment (mod 2^64)
+    _lib.call("hriemo_seed_bump", _p(seed_word(device)), _stream())      # golden-ratio increment (mod 2^64)
 
 
 def next_seed(training):
@@ -1936,6 +1953,8 @@ class FusionLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dx, db = ctx.saved_tensors
         ls, bs, ld, bd = ctx.shapes
+        if _is_one(g):                       # loss.backward(gradient=_ops.one(device)): the kernel's gradients are the answer
+            return dx.to(ld).view(ls), (db.to(bd).view(bs) if db is not None else None), None, None, None, None, None
         gl = (dx * g).to(ld).view(ls)
         gb = (db * g).to(bd).view(bs) if db is not None else None
         return gl, gb, None, None, None, None, None
@@ -1965,6 +1984,8 @@ class FusionLossCEFn(torch.autograd.Function):
     def backward(ctx, g):
         dx, db = ctx.saved_tensors
         ls, bs, ld, bd = ctx.shapes
+        if _is_one(g):
+            return dx.to(ld).view(ls), (db.to(bd).view(bs) if db is not None else None), None, None, None, None
         gl = (dx * g).to(ld).view(ls)
         gb = (db * g).to(bd).view(bs) if db is not None else None
         return gl, gb, None, None, None, None
@@ -2010,25 +2031,30 @@ class ExpandFn(torch.autograd.Function):
     """queries[N_e,d] -> [B,N_e,d] bf16   (models/emotion_decoder.py:127)"""
 
     @staticmethod
-    def forward(ctx, q, B):
+    def forward(ctx, q, B, twin=False):
+        """twin: also return the fp32 copy [B,N_e,d] (the residual twin of the first decoder layer; not differentiable)"""
         _require_gpu(q)
         Ne, d = q.shape
         out = torch.empty((B, Ne, d), dtype=BF16, device=q.device)
+        out32 = torch.empty((B, Ne, d), dtype=torch.float32, device=q.device) if twin else None
         src = q.detach().float().contiguous()
-        _lib.call("hriemo_expand_rows", _p(src), _p(out), B, Ne * d, _stream())
+        _lib.call("hriemo_expand_rows", _p(src), _p(out), _p(out32), B, Ne * d, _stream())
         ctx.cfg = (B, Ne, d)
         ctx.params = (q,)
+        if twin:
+            ctx.mark_non_differentiable(out32)
+            return out, out32
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _d32=None):
         B, Ne, d = ctx.cfg
         g = _contig_bf16(dout).view(B, Ne * d)
         sink = GradSink(ctx.params)
         dq = sink.buf(ctx.params[0])
         colsum(g, dq.view(Ne * d), sink.fused)
         sink.done(after_flush=ctx.params)
-        return sink.ret(dq), None
+        return sink.ret(dq), None, None
 
 
 class RowDotFn(torch.autograd.Function):

@@ -392,10 +392,16 @@ __global__ void dropout_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict_
 }
 
 // out[b][e][:] = q[e][:]   (emotion_decoder.py:127)
-__global__ void expand_rows_kernel(const float* __restrict__ q, bf16_t* __restrict__ out, int B, long n) {
+__global__ void expand_rows_kernel(const float* __restrict__ q, bf16_t* __restrict__ out, float* __restrict__ out32, int B, long n) {
   const long total = (long)B * n;
-  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) out[v] = (bf16_t)q[v % n];
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long)gridDim.x * blockDim.x) {
+    const float x = q[v % n];
+    out[v] = (bf16_t)x;
+    if (out32 != nullptr) out32[v] = x;       // fp32 twin of the residual stream (a torch expand + copy launch before)
+  }
 }
+// dropout seed word of a captured step: += the 64-bit golden ratio, once per replay (a torch add launch before)
+__global__ void seed_bump_kernel(unsigned long long* seed) { if (threadIdx.x == 0) *seed += 0x9E3779B97F4A7C15ull; }
 
 // logits[r] = z[r,:] . w + b   (emotion_decoder.py:155)
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restrict__ Z, const float* __restrict__ Z32, const float* __restrict__ w,
@@ -1063,12 +1069,18 @@ extern "C" int hriemo_unpack_rows(const void* P16, const float* P32, const int* 
   return 0;
 }
 
-extern "C" int hriemo_expand_rows(const float* q, void* out, int B, long n, hipStream_t st) {
+extern "C" int hriemo_expand_rows(const float* q, void* out, float* out32, int B, long n, hipStream_t st) {
   HRIEMO_CHECK(B > 0 && n > 0, "expand: empty");
   long g = ((long)B * n + 255) / 256;
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(expand_rows_kernel, dim3((int)g), dim3(256), 0, st, q, (bf16_t*)out, B, n);
+  hipLaunchKernelGGL(expand_rows_kernel, dim3((int)g), dim3(256), 0, st, q, (bf16_t*)out, out32, B, n);
   HRIEMO_LAUNCH_CHECK("expand_rows_kernel");
+  return 0;
+}
+extern "C" int hriemo_seed_bump(unsigned long long* seed_dev, hipStream_t st) {
+  HRIEMO_CHECK(seed_dev != nullptr, "seed_bump: no seed word");
+  hipLaunchKernelGGL(seed_bump_kernel, dim3(1), dim3(64), 0, st, seed_dev);
+  HRIEMO_LAUNCH_CHECK("seed_bump_kernel");
   return 0;
 }
 

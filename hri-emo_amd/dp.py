@@ -255,7 +255,11 @@ class DataParallelStep:
         if scale is not None:
             loss = loss * scale
         self.buckets.wait_zeroed()
-        loss.backward()
+        if loss.is_cuda and scale is None:
+            from . import _ops
+            loss.backward(gradient=_ops.one(loss.device))      # the fused losses skip the multiply by this very tensor
+        else:
+            loss.backward()
         return loss.detach()
 
     def step_accumulated(self, micro_batches):

@@ -101,8 +101,11 @@ class EmotionDecoder(nn.Module):
         self.out_proj = nn.Linear(d_model, 1) if use_output_layer else None
 
     def _queries(self, B):
-        out = _ops.ExpandFn.apply(self.emotion_queries, B)                                                # :127
-        # fp32 twin of the broadcast queries (residual operand of the first layer; gradient flows via `out`)
+        # :127; the fp32 twin of the broadcast queries (residual operand of the first layer; gradient flows via `out`) comes from
+        # the same launch
+        if _ops.TWIN and _ops.precision() == "bf16" and self.emotion_queries.is_cuda:
+            return _ops.ExpandFn.apply(self.emotion_queries, B, True)
+        out = _ops.ExpandFn.apply(self.emotion_queries, B)
         out32 = self.emotion_queries.detach().float().unsqueeze(0).expand(B, -1, -1).contiguous() if _ops.TWIN else None
         return out, out32
 

@@ -204,7 +204,10 @@ int hriemo_cast_f32_to_bf16_batch(const void* jobs_host, int njobs, hriemo_strea
 int hriemo_cast_copy_batch(const void* jobs_host, int njobs, hriemo_stream_t stream);
 int hriemo_dropout_bf16(const void* X, void* Y, long M, int N, float p_drop, unsigned long long seed,
                         const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);                  /* emotion_decoder.py:58 */
-int hriemo_expand_rows(const float* q, void* out, int B, long n, hriemo_stream_t stream);  /* emotion_decoder.py:127 */
+/* emotion_decoder.py:127: out[b] = q for b < B, as bf16 and (out32 != NULL) as the fp32 twin of the residual stream */
+int hriemo_expand_rows(const float* q, void* out, float* out32, int B, long n, hriemo_stream_t stream);
+/* the device-resident dropout seed word of a captured step += 0x9E3779B97F4A7C15 (one launch per replay, inside the graph) */
+int hriemo_seed_bump(unsigned long long* seed_dev, hriemo_stream_t stream);
 int hriemo_rowdot_fwd(const void* Z, const float* Z32, const float* w, const float* b, float* out, int M, int d,
                       hriemo_stream_t stream);                                     /* emotion_decoder.py:155 */
 /* dw[d], db[1]: overwritten, or added to when accumulate != 0 (gradients accumulated straight into .grad) */
