@@ -179,6 +179,9 @@ def seed_word(device):
     return t
 
 
+DROP_LOG = None          # tests: a list that receives every dropout site of a forward in call order --
+                         # ("attn", seed, site, B, H, Lq, Lk, p, b_off) / ("rows", seed, site, M, N, p, row_off); the effective seed
+                         # is seed + the device seed word (tests/hashrng.py rebuilds the keep-masks from these)
 _ones = {}
 
 
@@ -705,6 +708,8 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=Fal
     cu = (cu_seqlens_q, cu_seqlens_k) int32 device tensors: q / k / v hold packed rows, Lq / Lk are the longest sequences"""
     o = torch.empty((q.shape[0], H * hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    if DROP_LOG is not None and p > 0:
+        DROP_LOG.append(("attn", seed, site, B, H, Lq, Lk, float(p), b_off))
     mb = None
     if want_bits and p > 0:
         mb = torch.empty(_lib.lib().hriemo_attn_mask_bytes(B, H, Lq, Lk) // 8, dtype=torch.int64, device=q.device)
@@ -794,6 +799,8 @@ def add_ln_fwd(g, x, gamma, beta, p, seed, site, row_off, x32=None, want32=False
     y32 = torch.empty((M, d), dtype=torch.float32, device=g.device) if want32 else None
     mean = torch.empty(M, dtype=torch.float32, device=g.device)
     rstd = torch.empty(M, dtype=torch.float32, device=g.device)
+    if DROP_LOG is not None and p > 0 and rows is None:
+        DROP_LOG.append(("rows", seed, site, M, d, float(p), row_off))
     if rows is not None:          # packed rows: the dropout hash is keyed by the row of the padded layout
         yq = ys = None
         ld = 0
@@ -1656,6 +1663,8 @@ class FFNLN(torch.autograd.Function):
         hd_ = h
         if p_mid > 0:
             hd_ = torch.empty_like(h)
+            if DROP_LOG is not None:
+                DROP_LOG.append(("rows", seed, site + 2, M, h.shape[1], float(p_mid), b_off * L))
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
         g = proj_fwd(hd_, sh, w2, w2_16, b2)

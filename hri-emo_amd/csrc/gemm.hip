@@ -585,6 +585,8 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
   }
   // (config 5, 320x128: 480 instead of 600 tiles for the 25600 x 768 outputs, is 3-8 % faster on those launches alone
   // but 0.1 ms slower inside the two-stream step -- kept as a tuning configuration, never picked)
+  static const bool t320 = [] { const char* e = getenv("HRIEMO_GEMM_320"); return e && e[0] == '1'; }();   // A/B switch, see above
+  if (t320 && N <= 1024 && M >= 16384 && M % 320 == 0) return 5;
   if (tb == 0) return (N >= 2048 && M >= 16384) ? 2 : 1;                       // NT
   return (N >= 2048 && M >= 16384) ? 2 : 1;                                    // NN
 }
