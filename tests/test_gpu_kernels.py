@@ -153,7 +153,7 @@ def test_gemm_group_tn_many_weight_gradients_in_one_launch(ops):
         assert torch.equal(out[8:].double().cpu(), ref)                              # accumulate = 0 overwrites
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(200, 136, 96), (1000, 768, 256), (25600, 3072, 768), (8192, 3072, 768), (384, 2048, 768)])
 def test_gemm_masked_dx_with_column_sums(ops, cfg, M, N, K):
     """dX = (dY . W) * (aux > 0) with the column sums of the stored tile out of the same launch (FFN1 bias gradient): dX exact on
@@ -175,7 +175,7 @@ def test_gemm_masked_dx_with_column_sums(ops, cfg, M, N, K):
         L.hriemo_gemm_force_config(-1)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_every_tile_config_and_persistent_walk(ops, cfg):
     """Each tile configuration forced in turn: ragged edges, every epilogue, and a problem with more tiles than
     resident blocks so the persistent walk (next-tile prefetch, private epilogue scratch) is exercised."""
@@ -183,7 +183,8 @@ def test_gemm_every_tile_config_and_persistent_walk(ops, cfg):
     L = _lib.lib()
     L.hriemo_gemm_force_config(cfg)
     try:
-        for (M, N, K) in [(200, 136, 96), (300, 264, 160), (8192, 4096, 128)]:
+        # (the 6- / 7-deep rings of configurations 6-8 need K > 320: shorter problems fall back to configuration 0 by design)
+        for (M, N, K) in [(200, 136, 96), (300, 264, 160), (8192, 4096, 128), (390, 776, 512), (70, 2056, 1032)]:
             A, W, b = ints((M, K), seed=11), ints((N, K), seed=12), ints((N,), seed=13)
             ref = A @ W.t() + b
             y = ops.linear_fwd(A.cuda().bfloat16(), W.cuda().bfloat16(), b.cuda(), relu=True)
