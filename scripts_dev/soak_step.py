@@ -25,6 +25,8 @@ if ragged:
     la, lt = torch.randint(200, 401, (B,), generator=g_), torch.randint(64, 129, (B,), generator=g_)
     batch = (batch[0], batch[1], (torch.arange(400)[None] >= la[:, None]).to(dev), (torch.arange(128)[None] >= lt[:, None]).to(dev), batch[4])
 names = {id(p): nm for nm, p in model.named_parameters()}
+if os.environ.get("VARLEN", "0") == "1":                   # the packed (varlen) bucket graph: surplus rows must never leak into a sum
+    H.set_varlen(True)
 dp.step(*batch)
 dp.capture(*batch)
 sw = _ops.seed_word(dev)
