@@ -16,14 +16,20 @@ def load_seq_feat(obj):
     return obj["hidden"].float(), obj["attention_mask"].long() == 0
 
 
-def collate_seq_batch(batch, loss_type="multi_label"):
+def collate_seq_batch(batch, loss_type="multi_label", pad_to=None):
     """list of (h_a[L_a,d], m_a[L_a], h_t[L_t,d], m_t[L_t], label) -> (h_a[B,La,d], mask_a[B,La], h_t[B,Lt,d],
     mask_t[B,Lt], labels); zero padding, padded positions masked True; labels [B] long (single_label) or [B,C]
-    float (multi_label)   (:191-232)"""
+    float (multi_label)   (:191-232).  pad_to=(La, Lt): pad to these lengths instead of the batch maxima -- every batch then
+    has one shape, which is what a captured step wants; in packed (varlen) mode the extra PAD rows cost nothing
+    (DataParallelStep.capture, INTEGRATION.md)."""
     B = len(batch)
     d = batch[0][0].shape[-1]
     La = max(s[0].shape[0] for s in batch)
     Lt = max(s[2].shape[0] for s in batch)
+    if pad_to is not None:
+        if pad_to[0] < La or pad_to[1] < Lt:
+            raise ValueError(f"collate_seq_batch: pad_to={tuple(pad_to)} is shorter than this batch's longest sequences ({La}, {Lt})")
+        La, Lt = int(pad_to[0]), int(pad_to[1])
     h_a, h_t = torch.zeros(B, La, d), torch.zeros(B, Lt, d)
     m_a, m_t = torch.ones(B, La, dtype=torch.bool), torch.ones(B, Lt, dtype=torch.bool)
     for i, (xa, ka, xt, kt, _) in enumerate(batch):

@@ -112,6 +112,14 @@ def test_collate_matches_reference_fixture_and_trim_and_bucketing():
         assert got.dtype == g[key].dtype and torch.equal(got, g[key]), key
     single = data.collate_seq_batch([(b[0], b[1], b[2], b[3], i % 4) for i, b in enumerate(batch)], "single_label")[4]
     assert single.dtype == torch.long and torch.equal(single, g["single"])
+    # pad_to: one shape for every batch (captured steps); the reference's batch is its top-left corner, the rest is PAD
+    La, Lt = h_a.shape[1], h_t.shape[1]
+    fa, fma, ft, fmt, _ = data.collate_seq_batch(batch, "multi_label", pad_to=(La + 5, Lt + 3))
+    assert fa.shape[1] == La + 5 and ft.shape[1] == Lt + 3 and torch.equal(fa[:, :La], h_a) and torch.equal(fmt[:, :Lt], m_t)
+    assert bool(fma[:, La:].all()) and bool(fmt[:, Lt:].all()) and float(fa[:, La:].abs().sum()) == 0.0
+    import pytest
+    with pytest.raises(ValueError, match="pad_to"):
+        data.collate_seq_batch(batch, "multi_label", pad_to=(La - 1, Lt))
     # stored masks carry PAD tails: audio valid extents 7,14,2,8 of 9,14,6,11 -> 14 stays; text 5,2,6,1 of 5,3,7,4 -> 6
     ta, tma, tt, tmt = data.trim_padding(h_a, m_a, h_t, m_t)
     assert ta.shape[1] == 14 and tt.shape[1] == 6 and torch.equal(ta, h_a[:, :14]) and torch.equal(tmt, m_t[:, :6])
