@@ -36,7 +36,8 @@ shapes_tn = [(3072, 768, 25600), (768, 3072, 25600), (768, 768, 25600), (2304, 7
 torch.manual_seed(0)
 res = {}
 ncfg = int(os.environ.get("NCFG", "6"))
-for cfg in range(ncfg):
+cfg_list = [int(x) for x in os.environ["CFGS"].split(",")] if "CFGS" in os.environ else list(range(ncfg))
+for cfg in cfg_list:
     ok, info = check(cfg)
     print(f"cfg {cfg}: exact={ok} {info or ''}", flush=True)
     if not ok: continue
@@ -59,7 +60,7 @@ print("layout  M      N      K     | " + " ".join(f"cfg{c}:us/TF   " for c in ra
 for k in keys:
     fl = 2.0 * k[1] * k[2] * k[3]
     row = []
-    for c in range(ncfg):
+    for c in cfg_list:
         us = res.get(k + (c,))
         row.append(f"{us:7.1f}/{fl/us/1e6:5.0f}" if us else "      -      ")
     print(f"{k[0]:3s} {k[1]:6d} {k[2]:6d} {k[3]:6d} | " + " ".join(row))
