@@ -1151,3 +1151,41 @@ def test_gradient_exchange_captured_inside_the_step_graph(H):
         dp.buckets.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_single_label_train_step_vs_oracle(H):
+    """The IEMOCAP trainer's single_label branch (train_fusion_seq_level_decoder.py:312-314,325-326,413-414): CrossEntropyLoss
+    on the logits + the beta regulariser, through hri_emo_amd.train.fusion_step_loss_single_label (one kernel) -- loss, logits and
+    every parameter gradient of the whole model against the fp32 oracle with torch's own F.cross_entropy, dropout 0."""
+    import torch.nn.functional as F
+    from hri_emo_amd.train import fusion_step_loss_single_label
+    torch.manual_seed(1234)
+    kw = dict(d_model=256, num_emotions=4, n_heads=8, dropout=0.0)
+    ref = O.FusionWithEmotionDecoder(**kw).train()
+    m = H.FusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(5, 90, 36, 256, 13)
+    labels = torch.randint(0, 4, (5,), generator=torch.Generator().manual_seed(14))
+
+    def step(model, dev, autocast=False):
+        to = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t)
+        model.zero_grad()
+        if autocast:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                logits, beta, _ = model(to(h_a), to(h_t), to(m_a), to(m_t))
+            logits, beta = logits.float(), beta.float()
+        else:
+            logits, beta, _ = model(to(h_a), to(h_t), to(m_a), to(m_t))
+        if dev == "cuda":
+            loss = fusion_step_loss_single_label(logits, beta, to(labels))
+        else:
+            loss = F.cross_entropy(logits, labels) - 0.01 * (beta * (1.0 - beta)).mean()
+        loss.backward()
+        return loss.detach(), logits.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+    loss_r, logits_r, gr = step(ref, "cpu")
+    _, _, gy = step(ref, "cpu", autocast=True)
+    loss_m, logits_m, gm = step(m, "cuda")
+    close(loss_m.reshape(1), loss_r.reshape(1), what="loss"); close(logits_m, logits_r, what="logits")
+    assert_per_parameter_grads(gm, gy, gr, exceptions={"beta_gate.mlp.0.weight": 0.15, "beta_gate.mlp.0.bias": 0.15}, what="single_label")

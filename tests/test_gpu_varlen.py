@@ -359,3 +359,45 @@ def test_packed_training_loop_end_to_end(H):
     for a, b in zip(*traj):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), traj      # bf16 path, weights diverge slowly over the six updates
     assert traj[0][-1] != traj[0][0]
+
+
+@pytest.mark.parametrize("case", ["all_full", "all_one", "single_utterance", "exact_bucket_multiple"])
+def test_captured_packed_step_edge_length_patterns(H, case):
+    """Bucket arithmetic at its edges: every sequence full length (the surplus sequence sits beyond B*L rows), every sequence one
+    position long, a batch of one utterance, a valid row count that is an exact multiple of the bucket size (the bucket must still
+    add at least one surplus row).  Loss and gradients = the padded eager step's."""
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(5)
+    d, ne = 128, 4
+    B, Ta, Tt = (1, 40, 16) if case == "single_utterance" else (4, 64, 32)
+    m = H.FusionWithEmotionDecoder(d_model=d, num_emotions=ne, n_heads=8, dropout=0.0).cuda().train()
+    g = torch.Generator().manual_seed(6)
+    h_a, h_t = torch.randn(B, Ta, d, generator=g).cuda(), torch.randn(B, Tt, d, generator=g).cuda()
+    y = (torch.rand(B, ne, generator=g) < 0.3).float().cuda()
+    if case == "all_full":
+        la, lt = [Ta] * B, [Tt] * B
+    elif case == "all_one":
+        la, lt = [1] * B, [1] * B
+    elif case == "single_utterance":
+        la, lt = [23], [9]
+    else:                      # bucket sizes are max(8, B*L // 64 // 8 * 8) = 8 rows here: 4 x 16 = 64 audio rows, 4 x 8 = 32 text rows
+        la, lt = [16] * B, [8] * B
+    m_a = (torch.arange(Ta)[None] >= torch.tensor(la)[:, None]).cuda()
+    m_t = (torch.arange(Tt)[None] >= torch.tensor(lt)[:, None]).cuda()
+    dp = DataParallelStep(m, fusion_step_loss, overlap=False)
+    dp.set_global_batch(B)
+    H.set_varlen(False)
+    ref_loss = float(dp.step(h_a, h_t, m_a, m_t, y))
+    ref = dp.buckets.flat.clone()
+    H.set_varlen(True)
+    dp.capture(h_a, h_t, m_a, m_t, y, lengths=(la, lt))
+    for _ in range(2):
+        loss = float(dp.step(h_a, h_t, m_a, m_t, y, lengths=(la, lt)))
+    torch.cuda.synchronize()
+    rows_a, rows_t = int(dp._pb["cu_a"][-1]), int(dp._pb["cu_t"][-1])
+    assert rows_a > sum(la) and rows_t > sum(lt) and rows_a - sum(la) <= Ta and rows_t - sum(lt) <= Tt, (rows_a, rows_t)
+    assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (case, loss, ref_loss)
+    rel = float((dp.buckets.flat - ref).norm() / ref.norm())
+    assert rel <= 1e-5, (case, rel)
+    dp.release_graph()
