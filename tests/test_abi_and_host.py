@@ -200,3 +200,44 @@ def test_hook_predicates_are_per_instance():
     assert not _ops.grad_hooks_active()
     _ops.unregister_hook_predicate(b)
     assert not _ops._hook_predicates
+
+
+def test_packed_bucket_plan_host_logic():
+    """dp.DataParallelStep._packed_key (no GPU needed): per modality the packed row count is rounded up to the next multiple of the
+    bucket size and always leaves at least one surplus row, never more than one full sequence of them; cu_seqlens = cumulative
+    valid lengths + the bucket's row count; lengths handed over and lengths read from the masks give the same plan; masks that are
+    not suffix-PAD, or an empty sequence, are refused"""
+    import types
+    import pytest
+    import torch
+    from hri_emo_amd import dp
+    B, La, Lt = 8, 400, 128
+    stub = types.SimpleNamespace(_pb={"B": B, "La": La, "Lt": Lt, "cu_a": torch.zeros(B + 2, dtype=torch.int32),
+                                      "cu_t": torch.zeros(B + 2, dtype=torch.int32)})
+    key = lambda m_a, m_t, lens=None: dp.DataParallelStep._packed_key(stub, m_a, m_t, lens)
+    g = torch.Generator().manual_seed(1)
+    ga, gt = max(8, (B * La) // dp._VARLEN_BUCKETS // 8 * 8), max(8, (B * Lt) // dp._VARLEN_BUCKETS // 8 * 8)
+    for trial in range(20):
+        la = torch.randint(1, La + 1, (B,), generator=g)
+        lt = torch.randint(1, Lt + 1, (B,), generator=g)
+        if trial == 0:
+            la[:], lt[:] = La, Lt                       # everything full length
+        if trial == 1:
+            la[:], lt[:] = ga // 2, gt // 2             # valid rows an exact multiple of the bucket size
+        m_a, m_t = torch.arange(La)[None] >= la[:, None], torch.arange(Lt)[None] >= lt[:, None]
+        ra, rt = key(m_a, m_t)
+        cu_a, cu_t = stub._pb["cu_a"].tolist(), stub._pb["cu_t"].tolist()
+        for rows, lens, L, gsz, cu in ((ra, la, La, ga, cu_a), (rt, lt, Lt, gsz_t := gt, cu_t)):
+            n = int(lens.sum())
+            assert rows % min(gsz, L) == 0 and n < rows <= n + min(gsz, L) and rows - n <= L, (trial, rows, n)
+            assert cu[0] == 0 and cu[1:B + 1] == torch.cumsum(lens, 0).tolist() and cu[B + 1] == rows
+        assert key(m_a, m_t, (la.tolist(), lt.tolist())) == (ra, rt)
+        assert stub._pb["cu_a"].tolist() == cu_a and stub._pb["cu_t"].tolist() == cu_t
+    hole = m_a.clone(); hole[0, 0] = True; hole[0, 1] = False
+    with pytest.raises(RuntimeError, match="suffix"):
+        key(hole, m_t)
+    empty = m_t.clone(); empty[3, :] = True
+    with pytest.raises(RuntimeError, match="suffix"):
+        key(m_a, empty)
+    with pytest.raises(ValueError, match="lengths"):
+        key(m_a, m_t, ([0] * B, [1] * B))
