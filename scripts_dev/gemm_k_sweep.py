@@ -30,3 +30,13 @@ for (M, N, cfg) in [(25600, 768, 1), (25600, 768, 2), (25600, 3072, 2), (25600, 
     print(f"NT M={M} N={N} cfg {cfg}: " + "  ".join(f"K={k}: {tr:.1f}/{ta:.1f}" for k, tr, ta in rows))
     print(f"    real: a = {a_r:.1f} us, b = {b_r * 1e3:.2f} ns per k ({peak_b / b_r * 100:.0f} % of peak in the loop);  aliased: a = {a_a:.1f} us, b = {b_a * 1e3:.2f} ns per k ({peak_b / b_a * 100:.0f} %)")
 L.hriemo_gemm_force_config(-1)
+# the same with the OUTPUT aliased as well (ldc = 0: every tile row stores to row 0): what is left of `a` is not store bandwidth
+for (M, N, cfg) in [(25600, 768, 1), (25600, 3072, 2)]:
+    L.hriemo_gemm_force_config(cfg)
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out = []
+    for K in (256, 768, 1536):
+        A = torch.randn(M, K, device=dev).bfloat16(); W = torch.randn(N, K, device=dev).bfloat16()
+        out.append((K, timeit(lambda: _ops.gemm(0, 0, M, N, K, A, 0, W, 0, y, N)), timeit(lambda: _ops.gemm(0, 0, M, N, K, A, 0, W, 0, y, 0))))
+    print(f"NT M={M} N={N} cfg {cfg}, operands aliased, output real / aliased: " + "  ".join(f"K={k}: {t1:.1f}/{t2:.1f}" for k, t1, t2 in out))
+L.hriemo_gemm_force_config(-1)
