@@ -343,3 +343,46 @@ def test_fusion_loss_ce_label_out_of_range_is_nan(lib):
     x = torch.randn(4, 3).cuda()
     loss = _ops.FusionLossCEFn.apply(x, None, torch.tensor([0, 2, 3, 1]).cuda(), 0, 0.0, 1.0)
     assert torch.isnan(loss).item()
+
+
+def test_batched_cast_and_copy_jobs_in_one_launch(lib):
+    """hriemo_cast_copy_batch / hriemo_cast_f32_to_bf16_batch: a table of jobs passed through kernel arguments -- fp32 -> bf16
+    casts (kind 0) and fp32 copies (kind 1) of different lengths incl. tails that are no multiple of 8 and more than 64 jobs --
+    each destination exactly bf16(src) / src, nothing written past a job's end"""
+    g = torch.Generator().manual_seed(3)
+    sizes = [8, 24, 2048, 2056, 5000, 768 * 96, 17 * 8, 100000] + [16 * (j + 1) for j in range(70)]
+    srcs = [torch.randn(n, generator=g).cuda() for n in sizes]
+    kinds = [(j % 3 == 1) * 1 for j in range(len(sizes))]
+    dsts = [torch.full((n + 8,), 7.0, dtype=torch.float32 if k else torch.bfloat16, device="cuda") for n, k in zip(sizes, kinds)]
+    jobs = torch.tensor([(s.data_ptr(), d.data_ptr(), n, k) for s, d, n, k in zip(srcs, dsts, sizes, kinds)], dtype=torch.int64)
+    lib.call("hriemo_cast_copy_batch", jobs.data_ptr(), len(sizes), ST())
+    torch.cuda.synchronize()
+    for s, d, n, k in zip(srcs, dsts, sizes, kinds):
+        assert torch.equal(d[:n], s if k else s.bfloat16()), (n, k)
+        assert bool((d[n:].float() == 7.0).all()), (n, k, "wrote past the end")
+    # the 3-column form: casts only
+    d2 = [torch.empty(n, dtype=torch.bfloat16, device="cuda") for n in sizes[:5]]
+    jobs3 = torch.tensor([(s.data_ptr(), d.data_ptr(), n) for s, d, n in zip(srcs, d2, sizes)], dtype=torch.int64)
+    lib.call("hriemo_cast_f32_to_bf16_batch", jobs3.data_ptr(), 5, ST())
+    for s, d in zip(srcs, d2):
+        assert torch.equal(d, s.bfloat16())
+
+
+def test_expand_rows_with_fp32_twin_and_seed_bump(lib):
+    """hriemo_expand_rows: out[b] = bf16(q) and, with a twin pointer, out32[b] = q (emotion_decoder.py:127);
+    hriemo_seed_bump: the device seed word += 0x9E3779B97F4A7C15 mod 2^64, once per launch"""
+    q = torch.randn(6, 768, generator=torch.Generator().manual_seed(4)).cuda()
+    B = 5
+    out, out32 = bf(B, 6, 768), f32(B, 6, 768)
+    lib.call("hriemo_expand_rows", P(q), P(out), P(out32), B, 6 * 768, ST())
+    assert torch.equal(out, q.bfloat16()[None].expand(B, -1, -1)) and torch.equal(out32, q[None].expand(B, -1, -1))
+    out_b = bf(B, 6, 768)
+    lib.call("hriemo_expand_rows", P(q), P(out_b), None, B, 6 * 768, ST())
+    assert torch.equal(out_b, out)
+    word = torch.tensor([0x7FFFFFFFFFFFFFF0], dtype=torch.int64, device="cuda")
+    want = 0x7FFFFFFFFFFFFFF0
+    for _ in range(3):
+        lib.call("hriemo_seed_bump", P(word), ST())
+        want = (want + 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
+    got = int(word.item()) & ((1 << 64) - 1)
+    assert got == want, (hex(got), hex(want))
