@@ -128,6 +128,23 @@ def cpu_baseline():
                       f"threads, median of the timed steps (<={n_all}) after 1 warm-up; one_thread_value: B={1 if heavy else 2}, 1 thread"}
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+    CHILD process (one rank per GPU) and hand its output and exit code through.  Nothing in this process has touched the GPU
+    yet (no HIP call, no torch.cuda.is_available()): it stays a plain launcher, and the ranks are children, never an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no WORLD_SIZE in the environment: launching " + " ".join(cmd[1:]))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     global CFG, T_A, T_T, FLOP_PER_UTT_FWD_BWD
     a = parse()
@@ -136,6 +153,8 @@ def main():
     T_A, T_T, FLOP_PER_UTT_FWD_BWD = wl["T_a"], wl["T_t"], wl["flop"]
     if a.batch_per_gpu is None:
         a.batch_per_gpu = wl["batch"]
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(a.gpus))          # `python bench.py --gpus N` run plainly: becomes the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -66,6 +66,7 @@ _SIGS = {
     "hriemo_sigmoid_beta": ("pppiip", "i"),
     "hriemo_fuse_fwd": ("ppppiiip", "i"),
     "hriemo_add_ln_bwd_partial_rows": ("ii", "i"),
+    "hriemo_rowops_force_variant": ("i", "i"),
     "hriemo_colsum_partial_rows": ("ii", "i"),
     "hriemo_colreduce_batch": ("pipip", "i"),
     "hriemo_debug_hog": ("iipp", "i"),

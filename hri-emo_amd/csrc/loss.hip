@@ -67,16 +67,27 @@ __device__ __forceinline__ void beta_reg(const float* __restrict__ beta, int b, 
   }
 }
 
-// loss = mean_b [logsumexp_c x[b, c] - x[b, label_b]] + reg(beta): torch.nn.CrossEntropyLoss() (mean reduction, no label
-// smoothing, no class weights) as the IEMOCAP trainer builds it (:413-414); d loss / d x = (softmax(x) - onehot(label)) / B.
-// One thread per sample (C = number of emotion classes, a handful); labels outside [0, C) poison the loss with NaN instead of
-// reading out of bounds (torch raises for them on the host; a kernel cannot).
+// loss = mean over the labelled samples of [logsumexp_c x[b, c] - x[b, label_b]] + reg(beta): torch.nn.CrossEntropyLoss() (mean
+// reduction, no label smoothing, no class weights, ignore_index = -100) as the IEMOCAP trainer builds it (:413-414);
+// d loss / d x = (softmax(x) - onehot(label)) / n_labelled.  A sample whose label is -100 is skipped like the reference skips it:
+// no loss term, zero gradient, not counted in the mean (every sample ignored: 0 / 0 = NaN, as torch); the beta regulariser stays a
+// mean over all B samples.  One thread per sample (C = number of emotion classes, a handful); any OTHER label outside [0, C)
+// poisons the loss with NaN instead of reading out of bounds (torch raises for them on the host; a kernel cannot).
+#define CE_IGNORE_INDEX (-100LL)
 __global__ __launch_bounds__(256) void fusion_loss_ce_kernel(const float* __restrict__ x, const long long* __restrict__ label,
                                                              const float* __restrict__ beta, int B, int C, int mode, float coef,
                                                              float scale, float* __restrict__ loss, float* __restrict__ dx,
                                                              float* __restrict__ dbeta) {
   __shared__ float red[4];
-  float acc = 0.f;
+  __shared__ float cnt[4];
+  float nl = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) nl += label[b] != CE_IGNORE_INDEX ? 1.f : 0.f;
+  nl = wave_sum(nl);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = nl;
+  __syncthreads();
+  const float n_lab = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
+  const float inv_n = 1.f / n_lab;                 // n_lab = 0: inf, and 0 * inf below is the NaN torch returns
+  float acc = 0.f, ce = 0.f;
   const float inv_b = 1.f / (float)B;
   for (int b = threadIdx.x; b < B; b += 256) {
     const float* xr = x + (long)b * C;
@@ -85,19 +96,23 @@ __global__ __launch_bounds__(256) void fusion_loss_ce_kernel(const float* __rest
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += __expf(xr[c] - m);
     const long long lb = label[b];
+    const bool ign = lb == CE_IGNORE_INDEX;
     const bool ok = lb >= 0 && lb < C;
     const float lse = m + __logf(se);
-    acc += ok ? (lse - xr[ok ? lb : 0]) * inv_b : __builtin_nanf("");
+    if (!ign) ce += ok ? (lse - xr[ok ? lb : 0]) : __builtin_nanf("");
     const float inv_se = 1.f / se;
-    for (int c = 0; c < C; ++c) dx[(long)b * C + c] = (__expf(xr[c] - m) * inv_se - ((long long)c == lb ? 1.f : 0.f)) * inv_b * scale;
+    for (int c = 0; c < C; ++c)
+      dx[(long)b * C + c] = ign ? 0.f : (__expf(xr[c] - m) * inv_se - ((long long)c == lb ? 1.f : 0.f)) * inv_n * scale;
     float g;
     beta_reg(beta, b, mode, coef, inv_b, acc, g);
     if (dbeta != nullptr) dbeta[b] = g * scale;
   }
+  ce = wave_sum(ce);
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = acc; cnt[threadIdx.x >> 6] = ce; }
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (((cnt[0] + cnt[1]) + (cnt[2] + cnt[3])) * inv_n + (red[0] + red[1]) + (red[2] + red[3])) * scale;
 }
 
 extern "C" int hriemo_fusion_loss(const float* logits, const float* targets, const float* pos_weight, const float* beta, int B, int Ne,

@@ -10,10 +10,14 @@ is launched from a post-accumulate-grad hook as soon as its last gradient has be
 collective with the rest of backward.  xGMI is point-to-point (7 links x ~153 GB/s), so few large buckets
 (default 32 MiB) beat many small ones.
 """
+import collections
+import logging
 import os
 
 import torch
 import torch.distributed as dist
+
+log = logging.getLogger("hri_emo_amd.dp")
 
 # gradient memset on the side stream beside the first kernels of the forward instead of in front of them: measured neutral
 # (8.18 vs 8.14-8.19 ms per step on one box), opt-in
@@ -21,6 +25,9 @@ _ZERO_BESIDE = os.environ.get("HRIEMO_ZERO_BESIDE", "0") == "1"
 # packed (varlen) graphs: the packed row count of a modality is rounded up to a multiple of (padded rows / this): finer = fewer
 # wasted rows, more distinct graphs over a run (DataParallelStep.capture)
 _VARLEN_BUCKETS = max(1, int(os.environ.get("HRIEMO_VARLEN_BUCKETS", "64")))
+# packed (varlen) graphs kept alive per captured step: one hipGraph + the buffers its kernels point into per distinct
+# (audio rows, text rows) bucket pair; beyond the cap the least recently replayed one is released (and re-captured if it returns)
+_VARLEN_MAX_GRAPHS = max(1, int(os.environ.get("HRIEMO_VARLEN_MAX_GRAPHS", "48")))
 
 
 class GradBuckets:
@@ -29,9 +36,17 @@ class GradBuckets:
     bf16 and cast back into the fp32 flat buffer (the 1/N average is applied in fp32).  A bf16 sum over N <= 8 ranks adds
     ~2^-9 relative rounding per addition on top of the bf16 backward that produced the gradients."""
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True, comm_dtype=torch.float32, force_exchange=False):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True, comm_dtype=torch.float32, force_exchange=False,
+                 launch_from="notify"):
         """force_exchange: install the hooks and run the collectives at world size 1 too (a one-rank all-reduce is the identity:
-        rehearses the exchange -- also captured inside a hipGraph -- on a one-GPU box)"""
+        rehearses the exchange -- also captured inside a hipGraph -- on a one-GPU box)
+        launch_from: the stream an EAGER step launches a bucket's collective from -- "notify": the stream the gradient-ready
+        notification came in on (it first waits for the other branch stream); "main": always the model's main stream (which first
+        waits for the notifying one and the side stream).  A captured step always uses the capture's origin stream."""
+        if launch_from not in ("notify", "main"):
+            raise ValueError("GradBuckets: launch_from is 'notify' or 'main'")
+        self.launch_from = launch_from
+        self._snap = None           # test hook (enable_launch_snapshots): the flat buffer as every collective saw it at launch
         self.params = [p for p in params if p.requires_grad]
         self.force_exchange = bool(force_exchange) and dist.is_initialized()
         self.group = group
@@ -93,6 +108,37 @@ class GradBuckets:
             if getattr(p, "_hriemo_grad_ready", None) == self._on_grad_sink:
                 del p._hriemo_grad_ready
 
+    # -- test hook: is every collective launched behind the kernels that produce its bucket? ------------
+    def enable_launch_snapshots(self, on=True):
+        """Test hook.  While enabled, every bucket is copied to a side buffer at the exact point its collective
+        is enqueued -- on the launching stream, in front of the all-reduce, eager and inside a capture alike.  At world size 1
+        the all-reduce is the identity, so after the step the side buffer must equal the flat gradient buffer bit for bit; a
+        collective launched before one of its gradients was produced leaves the words that were written later different
+        (``launch_snapshot_mismatches``).  That makes the ORDERING of the exchange testable on one GPU, which the values of a
+        one-rank exchange alone are not.  fp32 buckets only.  Enable BEFORE capture() to have the copies recorded in the graph."""
+        if on and self.comm_dtype != torch.float32:
+            raise ValueError("launch snapshots compare fp32 buckets")
+        self._snap = torch.zeros_like(self.flat) if on else None
+
+    def launch_snapshot_mismatches(self):
+        """after a finished step at world size 1 -> [(bucket, words that differ, first differing word's parameter name or index)];
+        empty = every collective saw the final gradients of its bucket"""
+        if self._snap is None:
+            raise RuntimeError("enable_launch_snapshots() first")
+        if self.world != 1:
+            raise RuntimeError("launch snapshots are compared at world size 1 (the all-reduce must be the identity)")
+        out = []
+        for bi, (s, e, _) in enumerate(self.buckets):
+            a, b = self._snap[s:e], self.flat[s:e]
+            ne = (a != b) & ~(torch.isnan(a) & torch.isnan(b))
+            n = int(ne.sum())
+            if n:
+                first = s + int(ne.nonzero()[0])
+                owner = next((i for i, p in enumerate(self.params)
+                              if self._offsets[id(p)] <= first < self._offsets[id(p)] + p.numel()), None)
+                out.append((bi, n, owner))
+        return out
+
     # -- hooks ---------------------------------------------------------------------------------
     def _launch(self, bi):
         s, e, _ = self.buckets[bi]
@@ -111,8 +157,9 @@ class GradBuckets:
             from . import _ops
             streams = _ops.branch_streams(self.flat.device)
             cur = torch.cuda.current_stream(self.flat.device)
-            if _ops.CAPTURING and _ops.CAPTURE_ORIGIN is not None:
-                main = _ops.CAPTURE_ORIGIN
+            capturing = _ops.CAPTURING and _ops.CAPTURE_ORIGIN is not None
+            if capturing or self.launch_from == "main":
+                main = _ops.CAPTURE_ORIGIN if capturing else streams[0]
                 for st in streams:
                     if st != main:
                         main.wait_stream(st)
@@ -125,6 +172,10 @@ class GradBuckets:
                     if st != cur:
                         cur.wait_stream(st)
         try:
+            if self._snap is not None:
+                # what the collective is about to read, copied on the launching stream directly in front of it: a launch that
+                # precedes the production of one of the bucket's gradients shows as a difference to the final buffer
+                self._snap[s:e].copy_(self.flat[s:e])
             if self.comm_dtype == torch.float32:
                 self._works.append((dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None))
             else:
@@ -228,13 +279,14 @@ class DataParallelStep:
 
     _capture_streams = {}         # device index -> the one stream every capture of this process records on
 
-    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True, comm_dtype=torch.float32, force_exchange=False):
+    def __init__(self, model, loss_fn, group=None, bucket_bytes=32 << 20, overlap=True, comm_dtype=torch.float32, force_exchange=False,
+                 launch_from="notify"):
         self.model, self.loss_fn = model, loss_fn
         self._keep = []
         self._exchange_in_graph = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype, force_exchange)
+        self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype, force_exchange, launch_from)
         self._graph = None
         self._static = None
         self._static_loss = None
@@ -312,7 +364,7 @@ class DataParallelStep:
                                    "replay) or run the padded path")
             dev = self._static[0].device
             B, La, Lt = h_a.shape[0], h_a.shape[1], h_t.shape[1]
-            self._pb = {"graphs": {}, "B": B, "La": La, "Lt": Lt,
+            self._pb = {"graphs": collections.OrderedDict(), "B": B, "La": La, "Lt": Lt,
                         "cu_a": torch.zeros(B + 2, dtype=torch.int32, device=dev), "cu_t": torch.zeros(B + 2, dtype=torch.int32, device=dev)}
             key = self._packed_key(m_a, m_t, lengths)
             rec = self._packed_graph(key)
@@ -365,9 +417,27 @@ class DataParallelStep:
         pb = self._pb
         rec = pb["graphs"].get(key)
         if rec is None:
+            while len(pb["graphs"]) >= _VARLEN_MAX_GRAPHS:
+                # bounded: a corpus with a wide length spread would otherwise accumulate a graph + its buffers per bucket pair
+                old_key, old = pb["graphs"].popitem(last=False)
+                torch.cuda.synchronize()
+                old.clear()
+                _ops.GRAPHS_ALIVE = max(1, _ops.GRAPHS_ALIVE - 1)
+                log.info("packed step: released the graph of bucket %s (cap %d)", old_key, _VARLEN_MAX_GRAPHS)
             seqs = (_ops.seq_bucket(pb["cu_a"], pb["B"], pb["La"], key[0]), _ops.seq_bucket(pb["cu_t"], pb["B"], pb["Lt"], key[1]))
-            graph, loss, keep = self._capture_graph(seqs)
+            # a bucket met inside step() runs two eager warm-up passes + the capture pass; each draws dropout seeds from torch's
+            # CPU generator.  Ranks meet new buckets at different steps, so the generator is put back: its stream stays the one
+            # the caller (and every other rank) sees, as _ops.next_seed documents.
+            rng = torch.get_rng_state() if self._graph is not None else None
+            try:
+                graph, loss, keep = self._capture_graph(seqs)
+            finally:
+                if rng is not None:
+                    torch.set_rng_state(rng)
             rec = pb["graphs"][key] = {"graph": graph, "loss": loss, "keep": keep, "seqs": seqs}
+            log.info("packed step: captured the graph of bucket (audio rows, text rows) = %s (%d alive)", key, len(pb["graphs"]))
+        else:
+            pb["graphs"].move_to_end(key)
         return rec
 
     def _capture_graph(self, seqs):
@@ -451,7 +521,10 @@ class DataParallelStep:
                     self._pb["cu_a"].copy_(self._mask_seen["cu"][0]); self._pb["cu_t"].copy_(self._mask_seen["cu"][1])
                 else:
                     key = self._packed_key(m_a, m_t, lengths)
-                    self._mask_seen = {"key": seen, "val": key, "cu": (self._pb["cu_a"].clone(), self._pb["cu_t"].clone())}
+                    # the entry HOLDS the masks: while it is the cache entry their addresses cannot be handed to the next batch's
+                    # masks (same address + version 0 would otherwise pass for "the same tensors" with other lengths inside)
+                    self._mask_seen = {"key": seen, "val": key, "cu": (self._pb["cu_a"].clone(), self._pb["cu_t"].clone()),
+                                       "masks": (m_a, m_t)}
                 for s, t in zip(self._static, (h_a, h_t, m_a, m_t, y)):
                     if s is not None and t is not None and s.data_ptr() != t.data_ptr():
                         s.copy_(t)

@@ -250,9 +250,10 @@ int hriemo_gate_input_pooled(const float* a_pool, const float* t_pool, void* gat
 int hriemo_fusion_loss(const float* logits, const float* targets, const float* pos_weight, const float* beta, int B, int Ne,
                        int reg_mode, float reg_coef, float scale, float* loss, float* dlogits, float* dbeta, hriemo_stream_t stream);
 /* Single-label variant, torch.nn.CrossEntropyLoss() as scripts/fusion/train_fusion_seq_level_decoder.py:413-414 builds it (mean
- * over the batch, no class weights, no label smoothing), plus the same beta regulariser (:325-326): labels[B] are int64 class
- * indices in [0, C) (an index outside poisons the loss with NaN instead of reading out of bounds).  Writes loss[1],
- * dlogits[B,C] = (softmax - onehot)/B * scale, dbeta[B] (may be NULL). */
+ * over the labelled samples, no class weights, no label smoothing, ignore_index = -100), plus the same beta regulariser (:325-326,
+ * a mean over all B): labels[B] are int64 class indices in [0, C), or -100 for a sample the criterion skips (no loss term, zero
+ * gradient, not counted in the mean; all of them skipped: NaN, as torch); any other index outside [0, C) poisons the loss with NaN
+ * instead of reading out of bounds.  Writes loss[1], dlogits[B,C] = (softmax - onehot)/n_labelled * scale, dbeta[B] (may be NULL). */
 int hriemo_fusion_loss_ce(const float* logits, const long long* labels, const float* beta, int B, int C, int reg_mode,
                           float reg_coef, float scale, float* loss, float* dlogits, float* dbeta, hriemo_stream_t stream);
 int hriemo_scalar_gate_dx(const void* dH, int Lf, const float* beta, int is_a, const float* dpool, const float* cnt,
@@ -273,6 +274,11 @@ int hriemo_adamw_flat(float* p, const float* g, float* m, float* v, long n, floa
  * nseg | accumulate << 8 | first_block << 32, out0, out1, out2} with first_block the running sum of
  * nseg * ceil(w/32) over the preceding jobs and nblocks the total.  Deterministic (fixed summation order). */
 int hriemo_add_ln_bwd_partial_rows(int M, int d);
+/* Tuning / test hook: 0 (default) = LayerNorm(x + dropout(g)) forward and backward run the quad-mapped, software-pipelined kernels
+ * where they are built (d <= 1024, fp32 twin in and out, no MX copy); 1 = the chunk-mapped kernels everywhere.  Both mappings
+ * draw the same dropout masks and differ by the summation order of the row statistics only.  Set it before any workspace is sized
+ * (hriemo_add_ln_bwd_workspace_bytes / _partial_rows follow the variant). */
+int hriemo_rowops_force_variant(int variant);
 int hriemo_colsum_partial_rows(int M, int N);
 int hriemo_colreduce_batch(const void* jobs_host, int njobs, void* jobs_dev, int nblocks, hriemo_stream_t stream);
 /* tuning hook: `blocks` CUs made unavailable for ~`micros` us (stands in for a collective running beside the step) */

@@ -345,6 +345,29 @@ def test_fusion_loss_ce_label_out_of_range_is_nan(lib):
     assert torch.isnan(loss).item()
 
 
+def test_fusion_loss_ce_skips_ignore_index_like_torch(lib):
+    """nn.CrossEntropyLoss() (the IEMOCAP trainer's criterion, train_fusion_seq_level_decoder.py:413-414) skips samples labelled
+    -100 (ignore_index): no loss term, zero gradient, mean over the labelled samples only; every sample ignored gives NaN"""
+    from hri_emo_amd import _ops
+    g = torch.Generator().manual_seed(11)
+    for B, C in ((9, 4), (300, 6)):
+        x = (torch.randn(B, C, generator=g) * 3).requires_grad_(True)
+        lab = torch.randint(0, C, (B,), generator=g)
+        lab[::3] = -100
+        beta = torch.rand(B, 1, generator=g).requires_grad_(True)
+        ref = F.cross_entropy(x, lab) - 0.01 * (beta * (1 - beta)).mean()
+        ref.backward()
+        xd, bd = x.detach().cuda().requires_grad_(True), beta.detach().cuda().requires_grad_(True)
+        loss = _ops.FusionLossCEFn.apply(xd, bd, lab.cuda(), 1, 0.01, 1.0)
+        loss.backward()
+        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        assert (xd.grad.cpu() - x.grad).abs().max() <= 2e-6 * max(1.0, x.grad.abs().max().item())
+        assert (xd.grad.cpu()[::3] == 0).all()
+        assert (bd.grad.cpu() - beta.grad).abs().max() <= 1e-5 * max(1e-3, beta.grad.abs().max().item())
+    x = torch.randn(4, 3).cuda()
+    assert torch.isnan(_ops.FusionLossCEFn.apply(x, None, torch.full((4,), -100).cuda(), 0, 0.0, 1.0)).item()
+
+
 def test_batched_cast_and_copy_jobs_in_one_launch(lib):
     """hriemo_cast_copy_batch / hriemo_cast_f32_to_bf16_batch: a table of jobs passed through kernel arguments -- fp32 -> bf16
     casts (kind 0) and fp32 copies (kind 1) of different lengths incl. tails that are no multiple of 8 and more than 64 jobs --

@@ -289,6 +289,68 @@ def test_captured_packed_step_serves_every_batch(H):
     dp.release_graph()
 
 
+def test_packed_step_reads_the_lengths_of_a_batch_that_reuses_freed_mask_addresses(H):
+    """`dp.step(*make_batch())` -- every batch dropped before the next one is built, so the new masks get the freed
+    addresses (and `_version` 0) of the old ones.  With lengths=None the step must still read THIS batch's lengths, not a cached
+    cu_seqlens of the previous batch: every step equals the padded eager step of its own batch."""
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    B, Ta, Tt, d = 4, 96, 40, 128
+    dp = DataParallelStep(m, fusion_step_loss, overlap=False)
+    dp.set_global_batch(B)
+    specs = [(31, 30, 10), (32, 60, 20), (33, 30, 10), (34, 90, 35), (35, 10, 5)]
+    ref = []
+    H.set_varlen(False)
+    for s_, lo_a, lo_t in specs:
+        batch, _ = _ragged_batch(B, Ta, Tt, d, 4, s_, lo_a, lo_t)
+        ref.append((float(dp.step(*batch)), dp.buckets.flat.clone()))
+        del batch
+    H.set_varlen(True)
+    first, _ = _ragged_batch(B, Ta, Tt, d, 4, *specs[0])
+    dp.capture(*first)
+    del first
+    ptrs = set()
+    for i, (s_, lo_a, lo_t) in enumerate(specs):
+        batch, _ = _ragged_batch(B, Ta, Tt, d, 4, s_, lo_a, lo_t)        # the previous batch is gone: its blocks are free to be reused
+        ptrs.add((batch[2].data_ptr(), batch[3].data_ptr()))
+        loss = float(dp.step(*batch))                                    # lengths=None: read from the masks
+        torch.cuda.synchronize()
+        assert abs(loss - ref[i][0]) <= 1e-5 * max(1.0, abs(ref[i][0])), (i, loss, ref[i][0])
+        rel = float((dp.buckets.flat - ref[i][1]).norm() / ref[i][1].norm())
+        assert rel <= 1e-5, (i, rel)
+        del batch
+    dp.release_graph()
+
+
+def test_packed_bucket_graphs_are_bounded(H, monkeypatch):
+    """one hipGraph per distinct (audio rows, text rows) bucket pair must not grow without bound: beyond the cap the
+    least recently used graph is released, and a bucket that comes back is captured again with the same results"""
+    from hri_emo_amd import dp as dpmod
+    from hri_emo_amd.train import fusion_step_loss
+    monkeypatch.setattr(dpmod, "_VARLEN_MAX_GRAPHS", 2)
+    torch.manual_seed(3)
+    m = H.FusionWithEmotionDecoder(d_model=128, num_emotions=4, n_heads=8, dropout=0.0).cuda().train()
+    B, Ta, Tt, d = 4, 96, 40, 128
+    dp = dpmod.DataParallelStep(m, fusion_step_loss, overlap=False)
+    dp.set_global_batch(B)
+    batches = [_ragged_batch(B, Ta, Tt, d, 4, s_, lo_a, lo_t)[0] for s_, lo_a, lo_t in ((41, 20, 8), (42, 50, 20), (43, 90, 38))]
+    H.set_varlen(True)
+    dp.capture(*batches[0])
+    first = float(dp.step(*batches[0]))
+    g0 = dp.buckets.flat.clone()
+    rng = torch.get_rng_state()
+    for b in batches[1:]:
+        dp.step(*b)                                        # two new buckets: the first one's graph has to go
+    assert torch.equal(torch.get_rng_state(), rng)         # bucket captures inside step() leave torch's CPU generator alone
+    assert len(dp._pb["graphs"]) == 2
+    again = float(dp.step(*batches[0]))                    # captured afresh
+    torch.cuda.synchronize()
+    assert len(dp._pb["graphs"]) == 2 and again == first and torch.equal(dp.buckets.flat, g0)
+    dp.release_graph()
+
+
 def test_captured_packed_step_with_dropout_is_deterministic_per_seed(H):
     """dropout on, packed bucket graph: replays from the same seed word are bit-identical (bucket padding rows carry zeros and
     zero gradients, so nothing of them leaks into a sum), another seed gives another loss"""
