@@ -40,6 +40,16 @@ _SIGS = {
     "hriemo_gate_input_f32": ("pppiip", "i"),
     "hriemo_sigmoid_beta_f32": ("pppiip", "i"),
     "hriemo_fuse_f32": ("ppipippiiip", "i"),
+    "hriemo_split3_f32": ("pliipiiplp", "i"),
+    "hriemo_colsum_f32_workspace_bytes": ("ii", "l"),
+    "hriemo_colsum_f32": ("pliiplpipp", "i"),
+    "hriemo_add_ln_bwd_f32_workspace_bytes": ("ii", "l"),
+    "hriemo_add_ln_bwd_f32": ("ppppppppiiifpp", "i"),
+    "hriemo_attn_bwd_f32": ("plplplplplppplplplpiiiiip", "i"),
+    "hriemo_gate_dpre_f32": ("ppipipppiiip", "i"),
+    "hriemo_gate_input_bwd_f32": ("pppppiip", "i"),
+    "hriemo_gate_dy_f32": ("ppipppiiiip", "i"),
+    "hriemo_rowdot_bwd_f32": ("ppppppiiip", "i"),
     "hriemo_attn_probs": ("plplpppiiiiifQpIip", "i"),
     "hriemo_add_ln_fwd": ("pppppppppiiffQpIlp", "i"),
     "hriemo_add_ln_fwd_mx8": ("pppppppppiiffQpIlpplp", "i"),

@@ -14,6 +14,8 @@ import itertools
 import math
 import os as _os
 
+import threading
+
 import torch
 import torch.nn.functional as F
 
@@ -21,6 +23,7 @@ from . import _lib
 
 BF16 = torch.bfloat16
 _EPS = 1e-5
+_apply_tls = threading.local()
 
 
 # ----------------------------------------------------------------------------- plumbing
@@ -543,7 +546,8 @@ def gemm_mode():
 
 
 # ---- arithmetic of the whole path: 'bf16' (product path: bf16 GEMM operands, fp32 accumulate, fp32 residual twins) or 'fp32'
-# (inference only, hri-emo_amd/_fp32.py: the reference's fp32 arithmetic to 1e-3).  HRIEMO_PRECISION at first use, set_precision().
+# (hri-emo_amd/_fp32.py: the reference's fp32 arithmetic to 1e-3, forward and -- with dropout 0 -- backward).  HRIEMO_PRECISION at
+# first use, set_precision().
 PRECISION = None
 
 
@@ -1193,14 +1197,33 @@ def unpack_pair(p16, p32, seq):
 
 
 # ----------------------------------------------------------------------------- sub-layer Functions
-class SelfAttnLN(torch.autograd.Function):
+class _GradModeAware:
+    """Function.forward always runs with grad mode off, and ctx.needs_input_grad mirrors the inputs' requires_grad even under
+    torch.no_grad(): a forward that must know whether autograd is RECORDING this call (the fp32 mode saves its activations
+    only then, and refuses to train with dropout) reads the grad mode noted here at apply() time (thread-local)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        prev = getattr(_apply_tls, "grad_mode", None)
+        _apply_tls.grad_mode = torch.is_grad_enabled()
+        try:
+            return super().apply(*args, **kwargs)
+        finally:
+            _apply_tls.grad_mode = prev
+
+
+def recording(ctx):
+    """autograd will call this node's backward"""
+    return bool(getattr(_apply_tls, "grad_mode", True)) and any(ctx.needs_input_grad)
+
+
+class SelfAttnLN(_GradModeAware, torch.autograd.Function):
     """y = LN(x + drop(out_proj(MHA_core(in_proj(x))))) ; returns (y, probs|None)"""
 
     @staticmethod
     def forward(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
         if precision() == "fp32":
-            _fp32().guard(ctx, "self-attention sub-layer")
-            return _fp32().self_attn_ln(x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w)
+            return _fp32().self_attn_ln(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p)
         _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
@@ -1234,6 +1257,8 @@ class SelfAttnLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
+        if getattr(ctx, "fp32", False):
+            return _fp32().self_attn_ln_bwd(ctx, dy, dy32)
         x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
         B, L, d, H, hd, p, seed, site, b_off = ctx.cfg
         AB, AL, cu, RL, rows = ctx.packed
@@ -1266,7 +1291,7 @@ class SelfAttnLN(torch.autograd.Function):
         return (dx.view(B, L, d), None, r(dw_in), r(db_in), r(dw_out), r(db_out), r(dgamma), r(dbeta)) + (None,) * 8
 
 
-class CrossAttnLN(torch.autograd.Function):
+class CrossAttnLN(_GradModeAware, torch.autograd.Function):
     """y = LN(xq + drop(out_proj(MHA_core(Wq xq, Wkv xkv)))) ; returns (y, probs|None)"""
 
     @staticmethod
@@ -1278,8 +1303,7 @@ class CrossAttnLN(torch.autograd.Function):
         and hands the residual-path gradient of xq to join_q.  slots = (SharedGrad of dQ, SharedGrad of dK|dV): where the attention
         backward writes those gradients, so that they arrive at the projection's backward as column slices of ONE buffer."""
         if precision() == "fp32":
-            _fp32().guard(ctx, "cross-attention sub-layer")
-            return _fp32().cross_attn_ln(xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w)
+            return _fp32().cross_attn_ln(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p)
         _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(xq)
@@ -1360,6 +1384,8 @@ class CrossAttnLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy32, _dprobs):
+        if getattr(ctx, "fp32", False):
+            return _fp32().cross_attn_ln_bwd(ctx, dy, dy32)
         if ctx.q_pre and ctx.kv_pre and ctx.slots is not None:
             return CrossAttnLN._backward_shared(ctx, dy, dy32)
         xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits = ctx.saved_tensors
@@ -1641,15 +1667,14 @@ class KVProjFn(torch.autograd.Function):
         return dxkv.view(B, Lk, d), sink.ret(dw_in), None, None, None
 
 
-class FFNLN(torch.autograd.Function):
+class FFNLN(_GradModeAware, torch.autograd.Function):
     """y = LN(x + drop(W2 . drop_mid(relu(W1 x + b1)) + b2))"""
 
     @staticmethod
     def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off, seq=None):
         """seq: the Seq of packed rows (x is [1, N_valid, d]): keys the LayerNorm dropout by the rows of the padded layout"""
         if precision() == "fp32":
-            _fp32().guard(ctx, "feed-forward sub-layer")
-            return _fp32().ffn_ln(x, x32, w1, b1, w2, b2, gamma, beta, sh)
+            return _fp32().ffn_ln(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid)
         _require_fp32_masters(w1, b1, w2, b2, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
@@ -1681,6 +1706,8 @@ class FFNLN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dy32):
+        if getattr(ctx, "fp32", False):
+            return _fp32().ffn_ln_bwd(ctx, dy, dy32)
         x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma = ctx.saved_tensors
         B, L, d, p, p_mid, seed, site, b_off = ctx.cfg
         M, F = h.shape
@@ -1714,14 +1741,13 @@ class FFNLN(torch.autograd.Function):
         return (dx.view(B, L, d), None, r(dw1), r(db1), r(dw2), r(db2), r(dgamma), r(dbeta)) + (None,) * 7
 
 
-class BetaGateFn(torch.autograd.Function):
+class BetaGateFn(_GradModeAware, torch.autograd.Function):
     """(h_fusion, beta) = BetaGate(h_a, h_t, masks)  -- models/beta_gate_tacfn.py:68-118"""
 
     @staticmethod
     def forward(ctx, h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t):
-        if precision() == "fp32":
-            _fp32().guard(ctx, "BetaGate")
-            return _fp32().beta_gate(h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t)
+        if precision() == "fp32":            # -> (h_fusion as the fp32 tensor itself, beta)
+            return _fp32().beta_gate(ctx, h_a, h_a32, h_t, h_t32, ga, ba, gt, bt, w1, b1, w2, b2, sh, kpm_a, kpm_t)
         _require_fp32_masters(ga, ba, gt, bt, w1, b1, w2, b2)
         _require_gpu(h_a)
         h_a32, h_t32 = _c32(h_a32), _c32(h_t32)
@@ -1781,6 +1807,8 @@ class BetaGateFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dH, dbeta):
+        if getattr(ctx, "fp32", False):
+            return _fp32().beta_gate_bwd(ctx, dH, dbeta)
         (xa, xt, An, Tn, mean_a, rstd_a, mean_t, rstd_t, gin, a_pool, t_pool, cnt, hid, w, w1_16, w2_16, ga, gt, kpm_a,
          kpm_t, h_a32, h_t32) = ctx.saved_tensors
         B, La, Lt, L, d = ctx.cfg
@@ -2000,15 +2028,14 @@ class FusionLossCEFn(torch.autograd.Function):
         return gl, gb, None, None, None, None
 
 
-class LinearFn(torch.autograd.Function):
+class LinearFn(_GradModeAware, torch.autograd.Function):
     """y[..., N] (fp32) = x[..., K] . W[N,K]^T + b for any K (MOSEI projections: K = 74 / 300, padded to a
     multiple of 8 internally) -- models/mosei_fusion_with_emotion_decoder.py:41-42,63-65."""
 
     @staticmethod
     def forward(ctx, x, w, b, sh):
         if precision() == "fp32":
-            _fp32().guard(ctx, "Linear projection")
-            return _fp32().linear_any_k(x, w, b, sh)
+            return _fp32().linear_any_k(ctx, x, w, b, sh)
         _require_fp32_masters(w, b)
         _require_gpu(x)
         K = x.shape[-1]
@@ -2025,6 +2052,8 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if getattr(ctx, "fp32", False):
+            return _fp32().linear_any_k_bwd(ctx, dy)
         xb, w16 = ctx.saved_tensors
         shape, xdtype, K, N, M, kp = ctx.cfg
         dyb = dy.reshape(M, N).to(BF16).contiguous()
@@ -2036,7 +2065,7 @@ class LinearFn(torch.autograd.Function):
         return dx, dwp[:, :K].contiguous(), db, None
 
 
-class ExpandFn(torch.autograd.Function):
+class ExpandFn(_GradModeAware, torch.autograd.Function):
     """queries[N_e,d] -> [B,N_e,d] bf16   (models/emotion_decoder.py:127)"""
 
     @staticmethod
@@ -2050,14 +2079,20 @@ class ExpandFn(torch.autograd.Function):
         _lib.call("hriemo_expand_rows", _p(src), _p(out), _p(out32), B, Ne * d, _stream())
         ctx.cfg = (B, Ne, d)
         ctx.params = (q,)
+        ctx.fp32 = precision() == "fp32"      # fp32 mode: the decoder reads the fp32 copy and its gradient comes back through it
+        if ctx.fp32:
+            ctx.set_materialize_grads(False)
         if twin:
-            ctx.mark_non_differentiable(out32)
+            if not ctx.fp32:
+                ctx.mark_non_differentiable(out32)
             return out, out32
         return out
 
     @staticmethod
     def backward(ctx, dout, _d32=None):
         B, Ne, d = ctx.cfg
+        if ctx.fp32:
+            return _fp32().expand_bwd(dout, _d32, B, Ne, d, ctx.params[0]), None, None
         g = _contig_bf16(dout).view(B, Ne * d)
         sink = GradSink(ctx.params)
         dq = sink.buf(ctx.params[0])
@@ -2066,7 +2101,7 @@ class ExpandFn(torch.autograd.Function):
         return sink.ret(dq), None, None
 
 
-class RowDotFn(torch.autograd.Function):
+class RowDotFn(_GradModeAware, torch.autograd.Function):
     """logits[M] = z[M,d] . w[1,d] + b   (models/emotion_decoder.py:155)"""
 
     @staticmethod
@@ -2084,12 +2119,16 @@ class RowDotFn(torch.autograd.Function):
         ctx.save_for_backward(z2, z32v, wf)
         ctx.cfg = (B, Ne, d)
         ctx.params = (w, b)
+        ctx.fp32 = precision() == "fp32" and z32v is not None
         return out.view(B, Ne)
 
     @staticmethod
     def backward(ctx, dl):
         z2, z32v, wf = ctx.saved_tensors
         B, Ne, d = ctx.cfg
+        if ctx.fp32:                            # gradient of z in fp32, through the fp32 slot
+            dz32, dw, db = _fp32().rowdot_bwd(dl, z32v, wf, B, Ne, d)
+            return None, dz32, dw.view_as(ctx.params[0]), db.view_as(ctx.params[1])
         dl2 = dl.contiguous().float().view(-1)
         dz = torch.empty((B * Ne, d), dtype=BF16, device=z2.device)
         sink = GradSink(ctx.params)

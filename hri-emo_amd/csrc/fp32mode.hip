@@ -8,7 +8,11 @@
 //   * the attention cores (a few % of the FLOPs) run on the fp32 MFMA itself (v_mfma_f32_16x16x4_f32), S^T = K.Q^T so that the
 //     probabilities come out of the accumulator registers already in the B-operand layout of O^T = V^T.P^T;
 //   * LayerNorm, pooling, the gate and the fusion are fp32 row kernels.
-// Forward only (no dropout): training stays on the bf16 path.
+// Round 4: the backward of every piece in the same arithmetic (the IEMOCAP trainer runs fp32 without autocast,
+// scripts/fusion/train_fusion_seq_level_decoder.py:310-334): dX / dW on the same 3K-contraction bf16 GEMM (operands split along
+// the contraction -- rows for the transposed layouts, split3_kernel forms 2 / 3), attention backward on the fp32 MFMA, fp32
+// LayerNorm / gate / head backward row kernels.  Dropout is not built into these kernels: the mode trains with dropout = 0 (the
+// host side refuses p > 0 under autograd instead of silently dropping nothing).
 #include "common.h"
 #include <math.h>
 
@@ -356,6 +360,522 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float* __rest
   }
 }
 
+
+// ===================================================================================================== backward (round 4)
+// ------------------------------------------------------------------------------------------- operand splitting, general form
+// form 0: Y[M][3K] = [hi | mid | hi]   form 1: Y[M][3K] = [hi | hi | mid]      (contraction along the columns of X)
+// form 2: Y[3M][K] = [hi ; mid ; hi]   form 3: Y[3M][K] = [hi ; hi ; mid]      (contraction along the rows of X: dW = dY^T . X,
+//                                                                                 and the weight operand of dX = dY . W)
+// form 4: Y[M][6K] = [hi | mid | lo | hi | mid | hi]   form 5: Y[M][6K] = [hi | hi | hi | mid | mid | lo]   (x = hi + mid + lo EXACTLY)
+// form 6: Y[6M][K] = [hi ; mid ; lo ; hi ; mid ; hi]   form 7: Y[6M][K] = [hi ; hi ; hi ; mid ; mid ; lo]   (the same along the rows)
+// x is first multiplied by (mask > 0) when a mask is given (ReLU's derivative on the FFN's hidden gradient) and clamped at 0
+// when relu is set.  Pairing form 0 / 2 with form 1 / 3 yields hi.hi + mid.hi + hi.mid (2^-16 relative: the backward GEMMs).
+// Pairing form 4 / 6 with form 5 / 7 yields all six products down to 2^-24 (hi.hi + mid.hi + lo.hi + hi.mid + mid.mid + hi.lo):
+// what hri-emo_amd/_fp32.py uses for every GEMM of the mode since round 4.  The forward needs it -- one that is 4e-6 off flips the
+// sign of a ReLU pre-activation that lies that close to zero, and one flipped unit among the 40 x 4096 of a small batch moves its
+// weight row's gradient by 2e-3 of the whole matrix (measured: the 3-product forward left FFN first-layer gradients 0.6-5e-3
+// off, everything smooth at 1e-5) -- and the backward needs it on ill-conditioned weights: the closed-form fixtures amplify a
+// GEMM's error ~400x into the gate MLP's gradient (3-product backward 1.7e-3 there, the fp32 reference itself 2e-5).
+__global__ __launch_bounds__(256) void split3g_kernel(const float* __restrict__ X, long ldx, int M, int K, bf16_t* __restrict__ Y, int form,
+                                                      int relu, const float* __restrict__ mask, long ldm) {
+  const int kq = K >> 2;
+  const long nv = (long)M * kq;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+    const long m = v / kq;
+    const int k = (int)(v - m * kq) * 4;
+    f32x4 x = *(const f32x4*)(X + m * ldx + k);
+    if (mask != nullptr) {
+      const f32x4 mk = *(const f32x4*)(mask + m * ldm + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = mk[j] > 0.f ? x[j] : 0.f;
+    }
+    bf16x4 hi, mid, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = x[j];
+      if (relu) t = fmaxf(t, 0.f);
+      hi[j] = (bf16_t)t;
+      const float r1 = t - (float)hi[j];
+      mid[j] = (bf16_t)r1;
+      lo[j] = (bf16_t)(r1 - (float)mid[j]);
+    }
+    const bool wform = form & 1;          // weight-type order: hi, hi, mid
+    if (form >= 4) {
+      // six blocks, side by side (forms 4 / 5: block stride K inside a row of 6K) or stacked (forms 6 / 7: block stride M * K)
+      const long bs = form < 6 ? (long)K : (long)M * K;
+      bf16_t* y = form < 6 ? Y + m * 6L * K + k : Y + m * (long)K + k;
+      *(bf16x4*)y = hi;
+      *(bf16x4*)(y + bs) = wform ? hi : mid;
+      *(bf16x4*)(y + 2 * bs) = wform ? hi : lo;
+      *(bf16x4*)(y + 3 * bs) = wform ? mid : hi;
+      *(bf16x4*)(y + 4 * bs) = mid;
+      *(bf16x4*)(y + 5 * bs) = wform ? lo : hi;
+    } else if (form < 2) {
+      bf16_t* y = Y + m * 3L * K + k;
+      *(bf16x4*)y = hi;
+      *(bf16x4*)(y + K) = wform ? hi : mid;
+      *(bf16x4*)(y + 2 * K) = wform ? mid : hi;
+    } else {
+      bf16_t* y = Y + m * (long)K + k;
+      const long blk = (long)M * K;
+      *(bf16x4*)y = hi;
+      *(bf16x4*)(y + blk) = wform ? hi : mid;
+      *(bf16x4*)(y + 2 * blk) = wform ? mid : hi;
+    }
+  }
+}
+extern "C" int hriemo_split3_f32(const float* X, long ldx, int M, int K, void* Y, int form, int relu, const float* mask, long ldmask,
+                                 hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 8) == 0 && form >= 0 && form <= 7,
+               "split3_f32: bad shape, alignment or form");
+  HRIEMO_CHECK(mask == nullptr || (ldmask % 4 == 0 && ((uintptr_t)mask % 16) == 0), "split3_f32: mask alignment");
+  const long nv = (long)M * (K >> 2);
+  int grid = (int)((nv + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(split3g_kernel, dim3(grid), dim3(256), 0, st, X, ldx, M, K, (bf16_t*)Y, form, relu, mask, ldmask);
+  HRIEMO_LAUNCH_CHECK("split3g_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (double)M * K * 10.0);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- column sums of an fp32 matrix
+// out[n] (+)= sum_m X[m][n], fixed order: slice partials [S][N] (S row slices, one thread per column), then the slices in order
+__global__ __launch_bounds__(256) void colsum_f32_partial_kernel(const float* __restrict__ X, long ldx, int M, int N, int rows_per,
+                                                                 float* __restrict__ part, const float* __restrict__ mask, long ldm) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  if (mask != nullptr) {                    // x * (mask > 0): the bias gradient behind a ReLU
+    for (; r < r1; ++r) s0 += mask[(long)r * ldm + n] > 0.f ? X[(long)r * ldx + n] : 0.f;
+  } else {
+    for (; r + 4 <= r1; r += 4) {
+      s0 += X[(long)r * ldx + n]; s1 += X[(long)(r + 1) * ldx + n]; s2 += X[(long)(r + 2) * ldx + n]; s3 += X[(long)(r + 3) * ldx + n];
+    }
+    for (; r < r1; ++r) s0 += X[(long)r * ldx + n];
+  }
+  part[(long)blockIdx.y * N + n] = (s0 + s1) + (s2 + s3);
+}
+// out[seg][n] (+)= sum over p of part[p][seg * N + n]   (nseg segments side by side in every partial row)
+struct SegOut { float* o[3]; };
+__global__ __launch_bounds__(256) void colreduce_f32_kernel(const float* __restrict__ part, int np, int N, int nseg, SegOut out, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < np; ++p) s += part[(long)p * nseg * N + (long)seg * N + n];
+  float* o = out.o[seg] + n;
+  *o = accumulate ? *o + s : s;
+}
+extern "C" long hriemo_colsum_f32_workspace_bytes(int M, int N) { (void)M; return 64L * N * 4; }
+extern "C" int hriemo_colsum_f32(const float* X, long ldx, int M, int N, const float* mask, long ldmask, float* out, int accumulate,
+                                 float* workspace, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && N > 0 && out != nullptr && workspace != nullptr, "colsum_f32: bad arguments");
+  int slices = (M + 63) / 64;
+  if (slices > 64) slices = 64;
+  const int rows_per = (M + slices - 1) / slices;
+  slices = (M + rows_per - 1) / rows_per;
+  hipLaunchKernelGGL(colsum_f32_partial_kernel, dim3((N + 255) / 256, slices), dim3(256), 0, st, X, ldx, M, N, rows_per, workspace, mask, ldmask);
+  SegOut so; so.o[0] = out; so.o[1] = so.o[2] = nullptr;
+  hipLaunchKernelGGL(colreduce_f32_kernel, dim3((N + 255) / 256, 1), dim3(256), 0, st, workspace, slices, N, 1, so, accumulate);
+  HRIEMO_LAUNCH_CHECK("colsum_f32 kernels");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm(x + g) backward, fp32
+// dS = d loss / d (x + g) (= dX = dG without dropout); per-block column partials of dgamma = sum dY * xhat, dbeta = sum dY and
+// dbias = sum dS (the bias of the Linear that produced g).  The row statistics are recomputed (the row is in registers anyway).
+template <int NV4>
+__global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __restrict__ dY, const float* __restrict__ G, const float* __restrict__ X,
+                                                             const float* __restrict__ gamma, float* __restrict__ dS, float* __restrict__ part,
+                                                             int M, int d, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;            // [3][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nq = d >> 2;
+  const float invd = 1.f / (float)d;
+  f32x4 ag[NV4], ab[NV4], abias[NV4];
+#pragma unroll
+  for (int c = 0; c < NV4; ++c) ag[c] = ab[c] = abias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long row = (long)blockIdx.x * 4 + wave; row < M; row += (long)gridDim.x * 4) {
+    f32x4 s[NV4], dy[NV4];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV4; ++c) {
+      const int q = lane + 64 * c;
+      s[c] = dy[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (q < nq) {
+        s[c] = *(const f32x4*)(G + row * d + q * 4);
+        if (X != nullptr) s[c] += *(const f32x4*)(X + row * d + q * 4);
+        dy[c] = *(const f32x4*)(dY + row * d + q * 4);
+        sum += (s[c][0] + s[c][1]) + (s[c][2] + s[c][3]);
+      }
+    }
+    const float mu = wave_sum(sum) * invd;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV4; ++c)
+      if (lane + 64 * c < nq) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float t = s[c][j] - mu; sq += t * t; }
+      }
+    const float rstd = 1.f / sqrtf(wave_sum(sq) * invd + eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV4; ++c) {
+      const int q = lane + 64 * c;
+      if (q < nq) {
+        const f32x4 gm = *(const f32x4*)(gamma + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (s[c][j] - mu) * rstd;
+          const float dyg = dy[c][j] * gm[j];
+          c1 += dyg;
+          c2 += dyg * xh;
+          ag[c][j] += dy[c][j] * xh;
+          ab[c][j] += dy[c][j];
+          s[c][j] = xh;                 // xhat from here on
+          dy[c][j] = dyg;               // dy * gamma from here on
+        }
+      }
+    }
+    c1 = wave_sum(c1) * invd;
+    c2 = wave_sum(c2) * invd;
+#pragma unroll
+    for (int c = 0; c < NV4; ++c) {
+      const int q = lane + 64 * c;
+      if (q < nq) {
+        f32x4 ds;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ds[j] = rstd * (dy[c][j] - c1 - s[c][j] * c2); abias[c][j] += ds[j]; }
+        *(f32x4*)(dS + row * d + q * 4) = ds;
+      }
+    }
+  }
+  for (int sgm = 0; sgm < 3; ++sgm) {
+    const f32x4* a = sgm == 0 ? ag : (sgm == 1 ? ab : abias);
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int c = 0; c < NV4; ++c) {
+          const int q = lane + 64 * c;
+          if (q < nq) {
+            f32x4 v = a[c];
+            if (w != 0) v += *(const f32x4*)(red + sgm * d + q * 4);
+            *(f32x4*)(red + sgm * d + q * 4) = v;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* out = part + (long)blockIdx.x * 3 * d;
+  for (int t = threadIdx.x; t < 3 * d; t += 256) out[t] = red[t];
+}
+static int add_ln_bwd_f32_blocks(int M) { int g = (M + 3) / 4; return g > 512 ? 512 : g; }
+extern "C" long hriemo_add_ln_bwd_f32_workspace_bytes(int M, int d) { return (long)add_ln_bwd_f32_blocks(M) * 3 * d * 4; }
+extern "C" int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dgamma,
+                                     float* dbeta, float* dbias, int accumulate, int M, int d, float eps, float* workspace, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "add_ln_bwd_f32: d=%d must be a multiple of 4, at most 4096", d);
+  HRIEMO_CHECK(dY != nullptr && G != nullptr && gamma != nullptr && dS != nullptr && dgamma != nullptr && dbeta != nullptr && workspace != nullptr,
+               "add_ln_bwd_f32: missing operand");
+  const int nb = add_ln_bwd_f32_blocks(M);
+  hriemo_prof_begin(HP_ROWOPS, st);
+  if (d <= 1024) hipLaunchKernelGGL((add_ln_bwd_f32_kernel<4>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, workspace, M, d, eps);
+  else hipLaunchKernelGGL((add_ln_bwd_f32_kernel<16>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, workspace, M, d, eps);
+  HRIEMO_LAUNCH_CHECK("add_ln_bwd_f32_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (double)M * d * 16.0);
+  SegOut so; so.o[0] = dgamma; so.o[1] = dbeta; so.o[2] = dbias;
+  hipLaunchKernelGGL(colreduce_f32_kernel, dim3((d + 255) / 256, dbias != nullptr ? 3 : 2), dim3(256), 0, st, workspace, nb, d, 3, so, accumulate);
+  HRIEMO_LAUNCH_CHECK("colreduce_f32_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- attention backward on the fp32 MFMA
+// Two kernels, both in the forward kernel's register layouts (v_mfma_f32_16x16x4_f32, lane (i, g)), both deterministic:
+//  dQ: block = 64 queries of one (batch, head), key tiles of 64 through LDS.  S^T = K.Q^T and dP^T = V.dO^T leave the
+//      accumulators as [key 16n+4g+r][query i]; p = exp(s - lse), ds = p (dp - delta) with delta = rowsum(dO * O) (written out for
+//      the second kernel); dQ^T += K^T . dS^T is the forward's O^T += V^T . P^T with K for V.
+//  dK/dV: block = 64 keys, the keys on the lanes (K, V rows in registers), query tiles of 64 (Q, dO rows, lse, delta) through LDS:
+//      S = Q.K^T and dP = dO.V^T leave [query 16n+4g+r][key i]; dV^T += dO^T . P and dK^T += Q^T . dS contract over the tile's queries.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk,
+                                                              const float* __restrict__ V, long ldv, const float* __restrict__ O, long ldo,
+                                                              const float* __restrict__ dO, long lddo, const uint8_t* __restrict__ kpm,
+                                                              const float* __restrict__ lse, float* __restrict__ dQ, long lddq,
+                                                              float* __restrict__ delta, int H, int Lq, int Lk, float scale) {
+  constexpr int LDR = HD + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Ks = (float*)smem_raw;
+  float* Vs = Ks + 64 * LDR;
+  float* pad = Vs + 64 * LDR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q = min(q0 + i, Lq - 1);
+  const float* qp = Q + ((long)b * Lq + q) * ldq + h * HD;
+  const float* dop = dO + ((long)b * Lq + q) * lddo + h * HD;
+  const float* op = O + ((long)b * Lq + q) * ldo + h * HD;
+  float qf[HD / 4], dof[HD / 4];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < HD / 4; ++ks) {
+    qf[ks] = qp[4 * ks + g] * scale;
+    dof[ks] = dop[4 * ks + g];
+    dl += dof[ks] * op[4 * ks + g];
+  }
+  dl += __shfl_xor(dl, 16);
+  dl += __shfl_xor(dl, 32);
+  const float ls = lse[((long)b * H + h) * Lq + q];
+  if (g == 0 && q0 + i < Lq) delta[((long)b * H + h) * Lq + q0 + i] = dl;
+  f32x4 dq[HD / 16];
+#pragma unroll
+  for (int t = 0; t < HD / 16; ++t) dq[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* Kb = K + (long)b * Lk * ldk + h * HD;
+  const float* Vb = V + (long)b * Lk * ldv + h * HD;
+  for (int k0 = 0; k0 < Lk; k0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * (HD / 4); e += 256) {
+      const int r = e / (HD / 4), c = (e - r * (HD / 4)) * 4;
+      const int key = k0 + r;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (key < Lk) { kv = *(const f32x4*)(Kb + (long)key * ldk + c); vv = *(const f32x4*)(Vb + (long)key * ldv + c); }
+      *(f32x4*)(Ks + r * LDR + c) = kv;
+      *(f32x4*)(Vs + r * LDR + c) = vv;
+    }
+    if (tid < 64) {
+      const int key = k0 + tid;
+      pad[tid] = (key < Lk && (kpm == nullptr || kpm[(long)b * Lk + key] == 0)) ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      s[n] = dp[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 4; ++ks) {
+        s[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(16 * n + i) * LDR + 4 * ks + g], qf[ks], s[n], 0, 0, 0);
+        dp[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Vs[(16 * n + i) * LDR + 4 * ks + g], dof[ks], dp[n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(s[n][r] + pad[16 * n + 4 * g + r] - ls);
+        s[n][r] = p * (dp[n][r] - dl);            // dS^T[key][query]
+      }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < HD / 16; ++t)
+          dq[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(16 * n + 4 * g + r) * LDR + 16 * t + i], s[n][r], dq[t], 0, 0, 0);
+  }
+  if (q0 + i < Lq) {
+    float* dqp = dQ + ((long)b * Lq + q0 + i) * lddq + h * HD;
+#pragma unroll
+    for (int t = 0; t < HD / 16; ++t) {
+      f32x4 v = dq[t];
+      v *= scale;
+      *(f32x4*)(dqp + 16 * t + 4 * g) = v;
+    }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk,
+                                                               const float* __restrict__ V, long ldv, const float* __restrict__ dO, long lddo,
+                                                               const uint8_t* __restrict__ kpm, const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, float* __restrict__ dK, long lddk,
+                                                               float* __restrict__ dV, long lddv, int H, int Lq, int Lk, float scale) {
+  constexpr int LDR = HD + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* Qs = (float*)smem_raw;
+  float* Ds = Qs + 64 * LDR;
+  float* lss = Ds + 64 * LDR;          // [64] lse of the tile's queries (+inf past the end: p = 0)
+  float* dls = lss + 64;               // [64] delta
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const int key = min(k0 + i, Lk - 1);
+  const bool kvalid = (k0 + i < Lk) && (kpm == nullptr || kpm[(long)b * Lk + key] == 0);
+  const float kpad = kvalid ? 0.f : -INFINITY;
+  const float* kp = K + ((long)b * Lk + key) * ldk + h * HD;
+  const float* vp = V + ((long)b * Lk + key) * ldv + h * HD;
+  float kf[HD / 4], vf[HD / 4];
+#pragma unroll
+  for (int ks = 0; ks < HD / 4; ++ks) { kf[ks] = kp[4 * ks + g] * scale; vf[ks] = vp[4 * ks + g]; }
+  f32x4 dk[HD / 16], dv[HD / 16];
+#pragma unroll
+  for (int t = 0; t < HD / 16; ++t) dk[t] = dv[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* Qb = Q + (long)b * Lq * ldq + h * HD;
+  const float* Db = dO + (long)b * Lq * lddo + h * HD;
+  for (int q0 = 0; q0 < Lq; q0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * (HD / 4); e += 256) {
+      const int r = e / (HD / 4), c = (e - r * (HD / 4)) * 4;
+      const int qq = q0 + r;
+      f32x4 qv = {0.f, 0.f, 0.f, 0.f}, dv4 = {0.f, 0.f, 0.f, 0.f};
+      if (qq < Lq) { qv = *(const f32x4*)(Qb + (long)qq * ldq + c); dv4 = *(const f32x4*)(Db + (long)qq * lddo + c); }
+      *(f32x4*)(Qs + r * LDR + c) = qv;
+      *(f32x4*)(Ds + r * LDR + c) = dv4;
+    }
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      lss[tid] = qq < Lq ? lse[((long)b * H + h) * Lq + qq] : INFINITY;
+      dls[tid] = qq < Lq ? delta[((long)b * H + h) * Lq + qq] : 0.f;
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      s[n] = dp[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 4; ++ks) {
+        s[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 * n + i) * LDR + 4 * ks + g], kf[ks], s[n], 0, 0, 0);
+        dp[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[(16 * n + i) * LDR + 4 * ks + g], vf[ks], dp[n], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qr = 16 * n + 4 * g + r;
+        const float p = expf(s[n][r] + kpad - lss[qr]);       // [query qr][key i]
+        dp[n][r] = p * (dp[n][r] - dls[qr]);                  // dS
+        s[n][r] = p;
+      }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < HD / 16; ++t) {
+          dv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ds[(16 * n + 4 * g + r) * LDR + 16 * t + i], s[n][r], dv[t], 0, 0, 0);
+          dk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Qs[(16 * n + 4 * g + r) * LDR + 16 * t + i], dp[n][r], dk[t], 0, 0, 0);
+        }
+  }
+  if (k0 + i < Lk) {
+    float* dkp = dK + ((long)b * Lk + k0 + i) * lddk + h * HD;
+    float* dvp = dV + ((long)b * Lk + k0 + i) * lddv + h * HD;
+#pragma unroll
+    for (int t = 0; t < HD / 16; ++t) {
+      f32x4 v = dk[t];
+      v *= scale;                                   // S = scale Q.K^T: dK = scale . dS^T . Q (Q sits unscaled in LDS)
+      *(f32x4*)(dkp + 16 * t + 4 * g) = v;
+      *(f32x4*)(dvp + 16 * t + 4 * g) = dv[t];
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------- gate backward pieces (fp32)
+// h = w * A[:, :L] + (1 - w) * T[:, :L], beta = mean_d(w), w = sigmoid(pre)  (beta_gate_tacfn.py:92-116):
+//   dpre[b][c] = (sum_{l < L} dH[b][l][c] * (A - T)[b][l][c] + dbeta[b] / d) * w (1 - w)
+__global__ __launch_bounds__(256) void gate_dpre_f32_kernel(const float* __restrict__ dH, const float* __restrict__ A, int La,
+                                                            const float* __restrict__ T, int Lt, const float* __restrict__ w,
+                                                            const float* __restrict__ dbeta, float* __restrict__ dpre, int L, int d) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  float s0 = 0.f, s1 = 0.f;
+  int l = 0;
+  for (; l + 2 <= L; l += 2) {
+    s0 += dH[((long)b * L + l) * d + c] * (A[((long)b * La + l) * d + c] - T[((long)b * Lt + l) * d + c]);
+    s1 += dH[((long)b * L + l + 1) * d + c] * (A[((long)b * La + l + 1) * d + c] - T[((long)b * Lt + l + 1) * d + c]);
+  }
+  for (; l < L; ++l) s0 += dH[((long)b * L + l) * d + c] * (A[((long)b * La + l) * d + c] - T[((long)b * Lt + l) * d + c]);
+  const float wv = w[(long)b * d + c];
+  const float dw = (s0 + s1) + (dbeta != nullptr ? dbeta[b] / (float)d : 0.f);
+  dpre[(long)b * d + c] = dw * wv * (1.f - wv);
+}
+// gate input [a, t, |a - t|, a * t] (:87-89): da = g0 + sign(a - t) g2 + t g3, dt = g1 - sign(a - t) g2 + a g3   (sign(0) = 0, as torch.abs)
+__global__ __launch_bounds__(256) void gate_in_bwd_f32_kernel(const float* __restrict__ dgin, const float* __restrict__ a, const float* __restrict__ t,
+                                                              float* __restrict__ da, float* __restrict__ dt, int d) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  const float av = a[(long)b * d + c], tv = t[(long)b * d + c];
+  const float* g = dgin + (long)b * 4 * d;
+  const float sg = av > tv ? 1.f : (av < tv ? -1.f : 0.f);
+  da[(long)b * d + c] = g[c] + sg * g[2 * d + c] + tv * g[3 * d + c];
+  dt[(long)b * d + c] = g[d + c] - sg * g[2 * d + c] + av * g[3 * d + c];
+}
+// gradient that reaches the gate's LayerNorm output of one modality, row (b, l) of Lx:
+//   dY = (l < L ? wsel * dH[b][l] : 0) + (valid(b, l) ? dpool[b] / max(#valid(b), 1) : 0),  wsel = w (audio) or 1 - w (text)
+__global__ __launch_bounds__(256) void gate_dy_f32_kernel(const float* __restrict__ dH, const float* __restrict__ w, int is_a,
+                                                          const float* __restrict__ dpool, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ dY, int L, int Lx, int d) {
+  __shared__ float cnt_s;
+  const int b = blockIdx.y, l = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    float n = 0.f;
+    for (int k = tid; k < Lx; k += 64) n += (mask == nullptr || mask[(long)b * Lx + k] == 0) ? 1.f : 0.f;
+    n = wave_sum(n);
+    if (tid == 0) cnt_s = fmaxf(n, 1.f);
+  }
+  __syncthreads();
+  const bool valid = mask == nullptr || mask[(long)b * Lx + l] == 0;
+  const float inv = valid ? 1.f / cnt_s : 0.f;
+  for (int c = tid; c < d; c += 256) {
+    const float wv = w[(long)b * d + c];
+    float v = dpool[(long)b * d + c] * inv;
+    if (l < L) v += (is_a ? wv : 1.f - wv) * dH[((long)b * L + l) * d + c];
+    dY[((long)b * Lx + l) * d + c] = v;
+  }
+}
+// logits[m] = z[m] . w + b (emotion_decoder.py:155): dz = dl w, dw = sum_m dl[m] z[m], db = sum_m dl[m]; fixed summation order
+__global__ __launch_bounds__(256) void rowdot_bwd_f32_kernel(const float* __restrict__ dl, const float* __restrict__ Z, const float* __restrict__ w,
+                                                             float* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d,
+                                                             int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < d) {
+    const float wc = w[c];
+    float acc = 0.f;
+    for (int r = 0; r < M; ++r) {
+      const float gr = dl[r];
+      acc += gr * Z[(long)r * d + c];
+      dZ[(long)r * d + c] = gr * wc;
+    }
+    dw[c] = accumulate ? dw[c] + acc : acc;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float t = 0.f;
+    for (int r = 0; r < M; ++r) t += dl[r];
+    db[0] = accumulate ? db[0] + t : t;
+  }
+}
+
+extern "C" int hriemo_gate_dpre_f32(const float* dH, const float* A, int La, const float* T, int Lt, const float* w, const float* dbeta,
+                                    float* dpre, int B, int L, int d, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && L > 0 && d > 0 && L <= La && L <= Lt, "gate_dpre_f32: bad shape");
+  hipLaunchKernelGGL(gate_dpre_f32_kernel, dim3((d + 255) / 256, B), dim3(256), 0, st, dH, A, La, T, Lt, w, dbeta, dpre, L, d);
+  HRIEMO_LAUNCH_CHECK("gate_dpre_f32_kernel");
+  return 0;
+}
+extern "C" int hriemo_gate_input_bwd_f32(const float* dgin, const float* a_pool, const float* t_pool, float* da, float* dt, int B, int d,
+                                         hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && d > 0, "gate_input_bwd_f32: empty input");
+  hipLaunchKernelGGL(gate_in_bwd_f32_kernel, dim3((d + 255) / 256, B), dim3(256), 0, st, dgin, a_pool, t_pool, da, dt, d);
+  HRIEMO_LAUNCH_CHECK("gate_in_bwd_f32_kernel");
+  return 0;
+}
+extern "C" int hriemo_gate_dy_f32(const float* dH, const float* w, int is_a, const float* dpool, const unsigned char* mask, float* dY, int B,
+                                  int L, int Lx, int d, hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && L > 0 && Lx >= L && d > 0, "gate_dy_f32: bad shape");
+  hipLaunchKernelGGL(gate_dy_f32_kernel, dim3(Lx, B), dim3(256), 0, st, dH, w, is_a, dpool, mask, dY, L, Lx, d);
+  HRIEMO_LAUNCH_CHECK("gate_dy_f32_kernel");
+  return 0;
+}
+extern "C" int hriemo_rowdot_bwd_f32(const float* dl, const float* Z, const float* w, float* dZ, float* dw, float* db, int accumulate, int M,
+                                     int d, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && d > 0, "rowdot_bwd_f32: empty input");
+  hipLaunchKernelGGL(rowdot_bwd_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dl, Z, w, dZ, dw, db, M, d, accumulate);
+  HRIEMO_LAUNCH_CHECK("rowdot_bwd_f32_kernel");
+  return 0;
+}
+
 #define DISPATCH_HD_F32(hd, CALL)     \
   switch (hd) {                       \
     case 16: { CALL(16); } break;     \
@@ -403,5 +923,37 @@ extern "C" int hriemo_attn_probs_f32(const float* Q, long ldq, const float* K, l
   DISPATCH_HD_F32(head_dim, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("attn_probs_f32_kernel");
+  return 0;
+}
+
+extern "C" int hriemo_attn_bwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, const float* O, long ldo,
+                                   const float* dO, long lddo, const unsigned char* key_padding_mask, const float* lse, float* dQ, long lddq,
+                                   float* dK, long lddk, float* dV, long lddv, float* delta, int B, int H, int Lq, int Lk, int head_dim,
+                                   hipStream_t st) {
+  HRIEMO_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0 && lse != nullptr && delta != nullptr, "attn_bwd_f32: empty problem");
+  HRIEMO_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
+               "attn_bwd_f32: leading dimensions must be multiples of 4");
+  HRIEMO_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 &&
+                   ((uintptr_t)dQ % 16) == 0 && ((uintptr_t)dK % 16) == 0 && ((uintptr_t)dV % 16) == 0, "attn_bwd_f32: operands must be 16-byte aligned");
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  hriemo_prof_begin(HP_ATTN_BWD_DQ, st);
+#define CALL(HD)                                                                                                                          \
+  {                                                                                                                                       \
+    const int lds = (2 * 64 * (HD + 4) + 64) * 4;                                                                                         \
+    static bool attr = false;                                                                                                             \
+    if (!attr) {                                                                                                                          \
+      hipFuncSetAttribute((const void*)attn_bwd_dq_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
+      hipFuncSetAttribute((const void*)attn_bwd_dkv_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 256);               \
+      attr = true;                                                                                                                        \
+    }                                                                                                                                     \
+    hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<HD>), dim3((Lq + 63) / 64, B * H), dim3(256), lds, st, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, \
+                       key_padding_mask, lse, dQ, lddq, delta, H, Lq, Lk, scale);                                                        \
+    hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<HD>), dim3((Lk + 63) / 64, B * H), dim3(256), lds + 256, st, Q, ldq, K, ldk, V, ldv, dO, lddo, \
+                       key_padding_mask, lse, delta, dK, lddk, dV, lddv, H, Lq, Lk, scale);                                              \
+  }
+  DISPATCH_HD_F32(head_dim, CALL)
+#undef CALL
+  HRIEMO_LAUNCH_CHECK("attn_bwd_f32 kernels");
+  hriemo_prof_end(HP_ATTN_BWD_DQ, st, 14.0 * B * H * (double)Lq * Lk * head_dim);
   return 0;
 }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
   for (int t = threadIdx.x; t < 3 * d; t += 256) out[t] = red[t];
 }
 
-// ---- round 4: the same two kernels on a QUAD mapping (d <= 1024, fp32 twin in and out, no MX copy) -------------------------
+// ---- round 4: the same two kernels on a QUAD mapping (d = 256 * NQ <= 1024, fp32 twin in and out, no MX copy) -------------
 // The chunk mapping above gives lane l the 8-element chunks l, l + 64, ...: at d = 768 (96 chunks) lanes 32..63 idle on the second
 // chunk and every lane carries registers for two.  Here lane l owns the 4-element quads l, l + 64, ...: d = 768 is exactly three
 // quads on every lane (d = 1024: four), fp32 operands move as 16 bytes per lane and bf16 ones as 8, every wave-instruction a
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const bf16_t* __restric
 // written WITHOUT branches around memory operations: hipcc's wait insertion merges the pending-load state of the paths that
 // meet at a join conservatively, and one conditional load or store in the loop turned the counted wait in front of the first
 // use of the prefetched row into s_waitcnt vmcnt(0) (found in the ISA), which waits for the prefetch just issued.  So
-//   * lanes past the row's end (d = 128 / 256 / 512: part of a wave) are clamped onto the last quad: they load, compute and
-//     store what its owner does (a duplicate store of equal bytes) and are masked out of the sums by selects;
+//   * the mapping is built for rows that are whole multiples of 256 elements only (d = 256, 512, 768, 1024: all 64 lanes hold
+//     NQ full quads, every address is one per-lane base + immediates); other widths keep the chunk-mapped kernels;
 //   * the row after the last one is clamped onto row M - 1 (loaded, never consumed);
 //   * per-row scalars (mean, rstd, the packed-row -> padded-row map) are read with the row index in an SGPR, i.e. as scalar
 //     loads, which count on lgkmcnt and leave the vector-memory counter to the row data alone.
@@ -295,7 +295,7 @@ __device__ __forceinline__ uint32_t hash_row(const RowDrop& dr, long row_offset,
   return (uint32_t)(row_offset + (dr.rowmap != nullptr ? (long)dr.rowmap[row] : row));      // row in an SGPR: a scalar load
 }
 
-template <int NQ, bool EXACT>      // EXACT: d == 256 * NQ, every lane owns all its quads (addresses become one base + immediates)
+template <int NQ>                  // d == 256 * NQ
 __global__ __launch_bounds__(256, (NQ <= 2 ? 6 : NQ == 3 ? 5 : 4)) void add_ln_fwd_q_kernel(const bf16_t* __restrict__ G, const float* __restrict__ X32,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            bf16_t* __restrict__ Y, float* __restrict__ Y32,
@@ -306,14 +306,11 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 6 : NQ == 3 ? 5 : 4)) void add_ln_f
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nq = d >> 2;
   const float invd = 1.f / (float)d;
-  int qo[NQ];                   // element offset of this lane's quads (clamped), and whether the lane owns them
-  bool own[NQ];
+  int qo[NQ];                   // element offset of this lane's quads
   f32x4 gm[NQ], bt[NQ];
 #pragma unroll
   for (int c = 0; c < NQ; ++c) {
-    const int q = lane + 64 * c;
-    own[c] = EXACT || q < nq;
-    qo[c] = EXACT ? lane * 4 + 256 * c : min(q, nq - 1) * 4;
+    qo[c] = lane * 4 + 256 * c;
     gm[c] = *(const f32x4*)(gamma + qo[c]);
     bt[c] = *(const f32x4*)(beta + qo[c]);
   }
@@ -342,7 +339,7 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 6 : NQ == 3 ? 5 : 4)) void add_ln_f
       for (int j = 0; j < 4; ++j) {
         const float gv = kp[j] ? (float)gc[c][j] * dr.inv_keep : 0.f;
         s[c][j] = xc[c][j] + gv;
-        sum += own[c] ? s[c][j] : 0.f;
+        sum += s[c][j];
       }
     }
     const float mu = wave_sum(sum) * invd;
@@ -350,7 +347,7 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 6 : NQ == 3 ? 5 : 4)) void add_ln_f
 #pragma unroll
     for (int c = 0; c < NQ; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float t = s[c][j] - mu; sq += own[c] ? t * t : 0.f; }
+      for (int j = 0; j < 4; ++j) { const float t = s[c][j] - mu; sq += t * t; }
     const float rstd = rsqrtf(wave_sum(sq) * invd + eps);
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
@@ -368,7 +365,7 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 6 : NQ == 3 ? 5 : 4)) void add_ln_f
   }
 }
 
-template <int NQ, bool EXACT>
+template <int NQ>
 __global__ __launch_bounds__(256, (NQ <= 2 ? 4 : NQ == 3 ? 3 : 2)) void add_ln_bwd_q_kernel(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ G,
                                                            const float* __restrict__ X32, const float* __restrict__ gamma,
                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
@@ -382,13 +379,10 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 4 : NQ == 3 ? 3 : 2)) void add_ln_b
   const int nq = d >> 2;
   const float invd = 1.f / (float)d;
   int qo[NQ];
-  bool own[NQ];
   f32x4 ag[NQ], ab[NQ], abias[NQ], gm[NQ];
 #pragma unroll
   for (int c = 0; c < NQ; ++c) {
-    const int q = lane + 64 * c;
-    own[c] = EXACT || q < nq;
-    qo[c] = EXACT ? lane * 4 + 256 * c : min(q, nq - 1) * 4;
+    qo[c] = lane * 4 + 256 * c;
     ag[c] = ab[c] = abias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     gm[c] = *(const f32x4*)(gamma + qo[c]);
   }
@@ -426,7 +420,7 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 4 : NQ == 3 ? 3 : 2)) void add_ln_b
           kbits |= (kp[j] ? 1u : 0u) << (4 * c + j);
           const float gv = kp[j] ? (float)gc[c][j] * dr.inv_keep : 0.f;
           const float xh = (xc[c][j] + gv - mu) * rstd;
-          const float dyf = own[c] ? (float)dc[c][j] : 0.f;
+          const float dyf = (float)dc[c][j];
           const float dyg = dyf * gm[c][j];
           c1 += dyg;
           c2 += dyg * xh;
@@ -447,7 +441,7 @@ __global__ __launch_bounds__(256, (NQ <= 2 ? 4 : NQ == 3 ? 3 : 2)) void add_ln_b
           const float dyg = (float)dc[c][j] * gm[c][j];
           const float ds = rstd * (dyg - c1 - xh * c2);
           const float dg = k ? ds * dr.inv_keep : 0.f;
-          abias[c][j] += own[c] ? dg : 0.f;
+          abias[c][j] += dg;
           dsb[j] = (bf16_t)ds;
           dgb[j] = (bf16_t)dg;
         }
@@ -978,10 +972,10 @@ extern "C" int hriemo_rowops_force_variant(int v) {
   g_rowops_variant = v == 1 ? 1 : 0;
   return 0;
 }
-static bool use_quad(int d) { return g_rowops_variant == 0 && d <= 1024 && d % 4 == 0; }
+static bool use_quad(int d) { return g_rowops_variant == 0 && d <= 1024 && d % 256 == 0; }
 #define DISPATCH_NQ(d, CALL)                  \
   {                                           \
-    const int nq__ = ((d) / 4 + 63) / 64;     \
+    const int nq__ = (d) / 256;               \
     if (nq__ <= 1) { CALL(1); }               \
     else if (nq__ == 2) { CALL(2); }          \
     else if (nq__ == 3) { CALL(3); }          \
@@ -1004,19 +998,15 @@ static int num_cus_rowops() {
   return cus;
 }
 static int lnb_cap(int d) {
-  // [variant][slot]: the chunk-mapped kernel's occupancy depends on NCH, the quad-mapped one's on NQ (its RES forms differ by a
-  // few registers at most; the fp32-twin form, the one the model runs, is the one that is asked)
-  static int cache[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // chunk-mapped by NCH; quad-mapped by NQ, clamped / exact
+  static int cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // chunk-mapped by NCH; quad-mapped by NQ
   const bool quad = use_quad(d);
-  const int nch = (d / 8 + 63) / 64, nqs = (d / 4 + 63) / 64;
-  const int slot = quad ? nqs - 1 : (nch <= 1 ? 0 : nch <= 2 ? 1 : nch <= 4 ? 2 : 3);
-  int& c = cache[quad ? (d == 256 * nqs ? 2 : 1) : 0][slot];
+  const int nch = (d / 8 + 63) / 64;
+  const int slot = quad ? d / 256 - 1 : (nch <= 1 ? 0 : nch <= 2 ? 1 : nch <= 4 ? 2 : 3);
+  int& c = cache[quad ? 1 : 0][slot];
   if (c == 0) {
     int per = 0;
     if (quad) {
-#define CALL(N)                                                                                                              \
-  if (d == 256 * (N)) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)add_ln_bwd_q_kernel<N, true>, 256, (size_t)3 * d * 4); \
-  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)add_ln_bwd_q_kernel<N, false>, 256, (size_t)3 * d * 4)
+#define CALL(N) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)add_ln_bwd_q_kernel<N>, 256, (size_t)3 * d * 4)
       DISPATCH_NQ(d, CALL)
 #undef CALL
     } else {
@@ -1031,14 +1021,11 @@ static int lnb_cap(int d) {
 }
 // the quad-mapped forward is persistent as well: one block per resident slot, rows walked with a grid stride
 static int lnf_cap(int d) {
-  static int cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  const int nqs = (d / 4 + 63) / 64;
-  int& c = cache[d == 256 * nqs ? 1 : 0][nqs - 1];
+  static int cache[4] = {0, 0, 0, 0};
+  int& c = cache[d / 256 - 1];
   if (c == 0) {
     int per = 0;
-#define CALL(N)                                                                                            \
-  if (d == 256 * (N)) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)add_ln_fwd_q_kernel<N, true>, 256, 0); \
-  else hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)add_ln_fwd_q_kernel<N, false>, 256, 0)
+#define CALL(N) hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, (const void*)add_ln_fwd_q_kernel<N>, 256, 0)
     DISPATCH_NQ(d, CALL)
 #undef CALL
     if (per < 1) per = 4;
@@ -1057,11 +1044,7 @@ static int add_ln_fwd_impl(const void* G, const void* X, const float* X32, const
   dr.rowmap = row_index;
   hriemo_prof_begin(HP_ROWOPS, st);
   if (use_quad(d) && Yq == nullptr && X32 != nullptr && Y32 != nullptr) {        // the model's form: fp32 twin in and out
-#define CALL(N)                                                                                                                     \
-  if (d == 256 * (N))                                                                                                               \
-    hipLaunchKernelGGL((add_ln_fwd_q_kernel<N, true>), dim3(row_grid(M, lnf_cap(d))), dim3(256), 0, st, (const bf16_t*)G, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset); \
-  else                                                                                                                              \
-    hipLaunchKernelGGL((add_ln_fwd_q_kernel<N, false>), dim3(row_grid(M, lnf_cap(d))), dim3(256), 0, st, (const bf16_t*)G, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset)
+#define CALL(N) hipLaunchKernelGGL((add_ln_fwd_q_kernel<N>), dim3(row_grid(M, lnf_cap(d))), dim3(256), 0, st, (const bf16_t*)G, X32, gamma, beta, (bf16_t*)Y, Y32, mean, rstd, M, d, eps, dr, row_offset)
     DISPATCH_NQ(d, CALL)
 #undef CALL
   } else {
@@ -1110,11 +1093,7 @@ static int add_ln_bwd_impl(const void* dY, const void* G, const void* X, const f
   hriemo_prof_begin(HP_ROWOPS, st);
   if (dG == nullptr && p_drop == 0.f && dX != nullptr && use_quad(d) && X32 != nullptr) dG = dX;      // no dropout: dG == dX, one tensor, equal bytes twice
   if (use_quad(d) && X32 != nullptr && dX != nullptr && dG != nullptr) {
-#define CALL(N)                                                                                                                     \
-  if (d == 256 * (N))                                                                                                               \
-    hipLaunchKernelGGL((add_ln_bwd_q_kernel<N, true>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, X32, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset); \
-  else                                                                                                                              \
-    hipLaunchKernelGGL((add_ln_bwd_q_kernel<N, false>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, X32, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
+#define CALL(N) hipLaunchKernelGGL((add_ln_bwd_q_kernel<N>), dim3(nb), dim3(256), 3 * d * 4, st, (const bf16_t*)dY, (const bf16_t*)G, X32, gamma, mean, rstd, (bf16_t*)dX, (bf16_t*)dG, workspace, M, d, dr, row_offset)
     DISPATCH_NQ(d, CALL)
 #undef CALL
   } else {

@@ -18,17 +18,11 @@ class BetaGate(nn.Module):
         self._sh = _ops.Shadows()
 
     def _fwd_pair(self, a, a32, t, t32, mask_a, mask_t):
-        """h_fusion comes back bf16 only: it is consumed as a GEMM operand (the decoder's memory)."""
+        """h_fusion comes back bf16 only (fp32 mode: fp32): it is consumed as a GEMM operand (the decoder's memory)."""
         B, La, _ = a.shape
         Lt = t.shape[1]
         kpm_a, kpm_t = _ops.mask_u8(mask_a, B, La), _ops.mask_u8(mask_t, B, Lt)
-        if _ops.precision() == "fp32":
-            # called directly (not through Function.apply): h_fusion carries its fp32 twin as an attribute to the decoder
-            from hri_emo_amd import _fp32
-            if torch.is_grad_enabled() and (a.requires_grad or any(p.requires_grad for p in self.parameters())):
-                raise RuntimeError("BetaGate: HRIEMO_PRECISION=fp32 is an inference mode (forward only) -- run it under torch.no_grad()")
-            return _fp32.beta_gate(a, a32, t, t32, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight, self.norm_t.bias,
-                                   self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias, self._sh, kpm_a, kpm_t)
+        # (fp32 mode: the same Function; h_fusion then IS the fp32 tensor, read as such by the decoder and seen by autograd)
         return _ops.BetaGateFn.apply(a, a32, t, t32, self.norm_a.weight, self.norm_a.bias, self.norm_t.weight,
                                      self.norm_t.bias, self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight,
                                      self.mlp[2].bias, self._sh, kpm_a, kpm_t)
@@ -38,7 +32,4 @@ class BetaGate(nn.Module):
         a, a32 = _ops.as_pair(h_a)
         t, t32 = _ops.as_pair(h_t)
         h_fusion, beta = self._fwd_pair(a, a32, t, t32, mask_a, mask_t)
-        if _ops.precision() == "fp32" and out_dtype != torch.bfloat16:
-            from hri_emo_amd import _fp32
-            return _fp32.f32_of(h_fusion).to(out_dtype), beta
         return h_fusion.to(out_dtype), beta

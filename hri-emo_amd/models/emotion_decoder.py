@@ -103,7 +103,7 @@ class EmotionDecoder(nn.Module):
     def _queries(self, B):
         # :127; the fp32 twin of the broadcast queries (residual operand of the first layer; gradient flows via `out`) comes from
         # the same launch
-        if _ops.TWIN and _ops.precision() == "bf16" and self.emotion_queries.is_cuda:
+        if _ops.TWIN and self.emotion_queries.is_cuda:          # (fp32 mode: the fp32 copy carries the gradient back)
             return _ops.ExpandFn.apply(self.emotion_queries, B, True)
         out = _ops.ExpandFn.apply(self.emotion_queries, B)
         out32 = self.emotion_queries.detach().float().unsqueeze(0).expand(B, -1, -1).contiguous() if _ops.TWIN else None

@@ -275,7 +275,7 @@ int hriemo_adamw_flat(float* p, const float* g, float* m, float* v, long n, floa
  * nseg * ceil(w/32) over the preceding jobs and nblocks the total.  Deterministic (fixed summation order). */
 int hriemo_add_ln_bwd_partial_rows(int M, int d);
 /* Tuning / test hook: 0 (default) = LayerNorm(x + dropout(g)) forward and backward run the quad-mapped, software-pipelined kernels
- * where they are built (d <= 1024, fp32 twin in and out, no MX copy); 1 = the chunk-mapped kernels everywhere.  Both mappings
+ * where they are built (d = 256, 512, 768 or 1024, fp32 twin in and out, no MX copy); 1 = the chunk-mapped kernels everywhere.  Both mappings
  * draw the same dropout masks and differ by the summation order of the row statistics only.  Set it before any workspace is sized
  * (hriemo_add_ln_bwd_workspace_bytes / _partial_rows follow the variant). */
 int hriemo_rowops_force_variant(int variant);
@@ -290,9 +290,9 @@ int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const f
 /* (dgamma / dbeta: overwritten, or added to when accumulate != 0; both NULL: the per-block partial sums stay in `workspace`, rows
  * [B * ceil(L/32)] of [dgamma | dbeta] (2d floats each), for hriemo_colreduce_batch at the end of backward) */
 
-/* ---- fp32-tolerance inference mode (csrc/fp32mode.hip; host side hri-emo_amd/_fp32.py, HRIEMO_PRECISION=fp32).
+/* ---- fp32-tolerance mode, forward (csrc/fp32mode.hip; host side hri-emo_amd/_fp32.py, HRIEMO_PRECISION=fp32).
  * The reference's modules are fp32 nn.Modules throughout (models/cross_modal_block_tacfn.py:70-125, beta_gate_tacfn.py:68-118,
- * emotion_decoder.py:30-64,116-162); this mode reproduces them to 1e-3 (forward only, no dropout):
+ * emotion_decoder.py:30-64,116-162); this mode reproduces them to 1e-3 (no dropout; the backward follows below):
  *  - hriemo_split_bf16x3: X fp32 [M,K] (row stride ldx) -> Y bf16 [M,3K], x = hi + mid + ..: layout 0 (activations) [hi|mid|hi],
  *    layout 1 (weights) [hi|hi|mid]; relu != 0 applies max(x,0) first.  hriemo_gemm_bf16 over the 3K-long contraction with fp32
  *    output then gives hi.hi + mid.hi + hi.mid, the fp32 product to 2^-16 relative (nn.Linear, nn.MultiheadAttention in/out-proj);
@@ -315,6 +315,53 @@ int hriemo_gate_input_f32(const float* a_pool, const float* t_pool, float* gate_
 int hriemo_sigmoid_beta_f32(const float* pre, float* w, float* beta, int B, int d, hriemo_stream_t stream);
 int hriemo_fuse_f32(const float* w, const float* A, int La, const float* T, int Lt, float* H32, void* H16, int B, int L, int d,
                     hriemo_stream_t stream);
+
+/* ---- fp32-tolerance TRAINING step: the backward of the pieces above in the same arithmetic (round 4).  The IEMOCAP trainer runs
+ * the reference in fp32 without autocast (scripts/fusion/train_fusion_seq_level_decoder.py:310-334); with HRIEMO_PRECISION=fp32 the
+ * modules of hri-emo_amd/models keep every activation and every gradient in fp32 (host side hri-emo_amd/_fp32.py).  Dropout 0 only.
+ *  - hriemo_split3_f32: the operand split in four forms.  X fp32 [M,K] (row stride ldx), optionally times (mask > 0) (mask fp32
+ *    [M, ldmask]: ReLU's derivative) and / or clamped at 0 (relu) -> bf16
+ *      form 0: Y[M][3K] = [hi | mid | hi]      form 1: Y[M][3K] = [hi | hi | mid]       contraction along the columns of X
+ *      form 2: Y[3M][K] = [hi ; mid ; hi]      form 3: Y[3M][K] = [hi ; hi ; mid]       contraction along the rows of X
+ *      form 4: Y[M][6K] = [hi|mid|lo|hi|mid|hi]  form 5: Y[M][6K] = [hi|hi|hi|mid|mid|lo]  (x = hi + mid + lo exactly: six products,
+ *      form 6: Y[6M][K] = [hi;mid;lo;hi;mid;hi]  form 7: Y[6M][K] = [hi;hi;hi;mid;mid;lo]   2^-24 relative; what _fp32.py uses: no
+ *              ReLU pre-activation changes sign against fp32, ill-conditioned weights keep every gradient within 1e-3)
+ *    dX = dY . W is hriemo_gemm_bf16(ta 0, tb 1) on form 0 (4) of dY and form 3 (7) of W (K = 3 (6) N_out); dW = dY^T . X is
+ *    (ta 1, tb 1) on form 2 (6) of dY and form 3 (7) of X (K = 3 (6) M); fp32 output.
+ *  - hriemo_colsum_f32: out[n] (+)= sum_m X[m][n] * (mask[m][n] > 0) (bias gradients; mask fp32 [M, ldmask] or NULL), fixed
+ *    summation order; workspace >= hriemo_colsum_f32_workspace_bytes.
+ *  - hriemo_add_ln_bwd_f32: backward of Y = LayerNorm(G + X) * gamma + beta (X may be NULL): dS = d loss / d (G + X) [M,d]
+ *    (= dG = dX), dgamma / dbeta / dbias(= column sums of dS; may be NULL) overwritten or added to (accumulate); the row statistics
+ *    are recomputed from G + X.  workspace >= hriemo_add_ln_bwd_f32_workspace_bytes(M, d).
+ *  - hriemo_attn_bwd_f32: dQ, dK, dV of O = softmax(Q K^T / sqrt(hd) + key padding) V from Q, K, V, O, dO and the forward's lse, on
+ *    v_mfma_f32_16x16x4_f32; two kernels (dQ per 64 queries, dK / dV per 64 keys), no atomics, fixed order; delta: scratch
+ *    [B, H, Lq] floats (rowsum(dO * O), written by the first kernel for the second).  nn.MultiheadAttention, cross_modal_block_
+ *    tacfn.py:74-80,98-117, emotion_decoder.py:42,48-54.
+ *  - gate backward (beta_gate_tacfn.py:79-116): hriemo_gate_dpre_f32: dpre[B,d] = (sum_{l<L} dH (A - T) + dbeta / d) w (1 - w)
+ *    (dbeta [B] may be NULL); hriemo_gate_input_bwd_f32: gradients of the pooled means from d [a, t, |a-t|, a*t];
+ *    hriemo_gate_dy_f32: the gradient that reaches LayerNorm_x's output of one modality, dY[B,Lx,d] = (l < L ? wsel dH : 0) +
+ *    (valid ? dpool / max(#valid, 1) : 0), wsel = w (is_a) or 1 - w; the LayerNorm itself goes through hriemo_add_ln_bwd_f32.
+ *  - hriemo_rowdot_bwd_f32: logits = z . w + b (emotion_decoder.py:155): dZ[M,d] = dl w, dw[d] (+)= sum_m dl z, db[1] (+)= sum dl. */
+int hriemo_split3_f32(const float* X, long ldx, int M, int K, void* Y, int form, int relu, const float* mask, long ldmask,
+                      hriemo_stream_t stream);
+long hriemo_colsum_f32_workspace_bytes(int M, int N);
+int hriemo_colsum_f32(const float* X, long ldx, int M, int N, const float* mask, long ldmask, float* out, int accumulate,
+                      float* workspace, hriemo_stream_t stream);
+long hriemo_add_ln_bwd_f32_workspace_bytes(int M, int d);
+int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dgamma, float* dbeta,
+                          float* dbias, int accumulate, int M, int d, float eps, float* workspace, hriemo_stream_t stream);
+int hriemo_attn_bwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, const float* O, long ldo,
+                        const float* dO, long lddo, const unsigned char* key_padding_mask, const float* lse, float* dQ, long lddq,
+                        float* dK, long lddk, float* dV, long lddv, float* delta, int B, int H, int Lq, int Lk, int head_dim,
+                        hriemo_stream_t stream);
+int hriemo_gate_dpre_f32(const float* dH, const float* A, int La, const float* T, int Lt, const float* w, const float* dbeta, float* dpre,
+                         int B, int L, int d, hriemo_stream_t stream);
+int hriemo_gate_input_bwd_f32(const float* dgin, const float* a_pool, const float* t_pool, float* da, float* dt, int B, int d,
+                              hriemo_stream_t stream);
+int hriemo_gate_dy_f32(const float* dH, const float* w, int is_a, const float* dpool, const unsigned char* mask, float* dY, int B, int L,
+                       int Lx, int d, hriemo_stream_t stream);
+int hriemo_rowdot_bwd_f32(const float* dl, const float* Z, const float* w, float* dZ, float* dw, float* db, int accumulate, int M, int d,
+                          hriemo_stream_t stream);
 
 /* ---- per-kernel-class HIP-event timing on the launch stream (bench.py roofline leg) */
 int hriemo_prof_enable(int on);

@@ -59,6 +59,15 @@ def test_split3_reconstructs_to_2_pow_minus_16(H):
         assert float(rel.max()) <= 2.0 ** -15
     yr = _fp32.split3(-x.abs(), relu=True).float()
     assert float(yr.abs().max()) == 0.0
+    # forms 4 / 5 (the forward GEMMs): three parts that add up to the fp32 value EXACTLY, laid out for the six products
+    K = x.shape[1]
+    for form in (4, 5):
+        y = _fp32.split(x, form).double()
+        blk = [y[:, j * K:(j + 1) * K] for j in range(6)]
+        hi, mid, lo = (blk[0], blk[1], blk[2]) if form == 4 else (blk[0], blk[3], blk[5])
+        assert torch.equal(hi + mid + lo, x.double()), form
+        order = (hi, mid, lo, hi, mid, hi) if form == 4 else (hi, hi, hi, mid, mid, lo)
+        assert all(torch.equal(a, b) for a, b in zip(blk, order)), form
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 136, 96), (1024, 768, 768), (64, 256, 3072), (130, 2304, 768)])
@@ -71,13 +80,13 @@ def test_linear_x3_against_float64(H, M, N, K):
     y = _fp32.linear(x.cuda(), sh, wp, bp)
     ref = x.double() @ w.double().t() + b.double()
     err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
-    assert err <= 2e-5, err
+    assert err <= 2e-6, err              # six products of exact three-way splits: fp32-GEMM accuracy (the 3-product form: 5e-6)
     # what the bf16 operands alone would give on the same problem, for scale (printed with -s)
     e16 = float(((x.bfloat16().double() @ w.bfloat16().double().t() + b.double()) - ref).abs().max() / ref.abs().max())
     print(f"x3 linear {M}x{N}x{K}: max err / max|ref| = {err:.2e} (bf16 operands: {e16:.2e})")
     y2 = _fp32.linear(x.cuda(), sh, wp, bp, rows=(8, 72), relu_in=True)
     ref2 = x.double().clamp(min=0) @ w.double()[8:72].t() + b.double()[8:72]
-    assert float((y2.double().cpu() - ref2).abs().max() / ref2.abs().max()) <= 2e-5
+    assert float((y2.double().cpu() - ref2).abs().max() / ref2.abs().max()) <= 2e-6
 
 
 @pytest.mark.parametrize("B,H_,Lq,Lk,hd,masked", [(2, 8, 100, 40, 96, True), (3, 4, 33, 130, 64, True), (2, 2, 400, 128, 128, False),
@@ -268,14 +277,200 @@ def test_fusion_vs_oracle_seeded_fp32(H, B, Ta, Tt, d, ne, lf, ld):
     print(f"fp32 mode vs oracle B{B} Ta{Ta} Tt{Tt} d{d}: logits {e[0]:.2e} beta {e[1]:.2e} z {e[2]:.2e} maps {worst:.2e}")
 
 
-def test_fp32_mode_is_forward_only_and_says_so(H):
+def test_fp32_mode_contract(H):
     m = fusion(H, 128, 4).eval()
     g = load_golden("cfg1_eval_nomask")
-    with pytest.raises(RuntimeError, match="inference mode"):
-        m(cu(g["h_a"]), cu(g["h_t"]))                       # parameters require grad, autograd is recording
     with pytest.raises(ValueError):
         H.set_precision("fp64")
     # bf16 inputs are accepted (exact upcast) and come back as bf16
     with torch.no_grad():
         logits, beta, z = m(cu(g["h_a"]).bfloat16(), cu(g["h_t"]).bfloat16())
     assert z.dtype == torch.bfloat16 and logits.dtype == torch.float32
+    # eval under autograd (dropout inactive) records a graph; TRAIN mode with dropout > 0 is refused loudly -- the fp32 kernels
+    # do not drop, and silently training without dropout would not be the model that was asked for
+    logits, beta, z = m(cu(g["h_a"]), cu(g["h_t"]))
+    assert logits.requires_grad
+    with pytest.raises(NotImplementedError, match="dropout = 0"):
+        m.train()(cu(g["h_a"]), cu(g["h_t"]))
+    with torch.no_grad():
+        m.train()(cu(g["h_a"]), cu(g["h_t"]))              # nothing recorded: plain forward, allowed
+
+
+# ----------------------------------------------------------------------------- training step in fp32 (round 4)
+GRAD_TOL = 1e-3          # north_star: "within 1e-3 fp32"; per parameter, relative L2 against the fp32 reference
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _train_step(model, h_a, h_t, m_a, m_t, y):
+    h_a = h_a.clone().requires_grad_(True)
+    h_t = h_t.clone().requires_grad_(True)
+    logits, beta, z = model(h_a, h_t, m_a, m_t)
+    loss = O.train_step_loss(logits, beta, y)
+    model.zero_grad()
+    loss.backward()
+    return loss.detach(), logits.detach(), z.detach(), h_a.grad, h_t.grad, {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+
+def _check_step(H, g, h_a, h_t, m_a, m_t, d, ne, what, closed=True, kw=None):
+    """the trainer's step (train_fusion_seq_level_decoder.py:310-331, fp32, no autocast) with dropout 0: loss, logits, z, the input
+    gradients and EVERY parameter's gradient of the fp32 mode against the fp32 oracle on the same weights (relative L2 <= 1e-3
+    each); with the closed-form fixture weights the oracle is first tied to the gradient record the REFERENCE left in the
+    fixture (norm of every parameter's gradient, the bias / LayerNorm gradients in full), and so is the fp32 mode directly"""
+    kw = dict(kw or dict(d_model=d, num_emotions=ne, n_heads=8), dropout=0.0)
+    torch.manual_seed(1234)
+    ref = O.FusionWithEmotionDecoder(**kw).train()
+    if closed:
+        O.closed_form_init_(ref)
+    m = H.FusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    y = g["y"]
+    loss_r, logits_r, z_r, ga_r, gt_r, gr = _train_step(ref, h_a, h_t, m_a, m_t, y)
+    loss_m, logits_m, z_m, ga_m, gt_m, gm = _train_step(m, cu(h_a), cu(h_t), cu(m_a), cu(m_t), cu(y))
+    close(loss_m.reshape(1), loss_r.reshape(1), 1e-5, "loss"); close(logits_m, logits_r, what="logits"); close(z_m, z_r, what="z")
+    rows = sorted(((_rel(gm[n], gr[n]), n) for n in gr), reverse=True)
+    for n, p in m.named_parameters():
+        assert p.grad.dtype == torch.float32 and p.grad.shape == p.shape and bool(torch.isfinite(p.grad).all()), n
+    assert rows[0][0] <= GRAD_TOL, (what, "worst five:", rows[:5])
+    ea, et = _rel(ga_m, ga_r), _rel(gt_m, gt_r)
+    assert ea <= GRAD_TOL and et <= GRAD_TOL, (what, "input gradients", ea, et)
+    if closed:
+        close(loss_r.reshape(1), g["loss"], 1e-5, "oracle loss vs golden")
+        for n in gr:
+            ref_norm = float(g["g.norm." + n])
+            assert abs(float(gm[n].double().norm()) - ref_norm) <= GRAD_TOL * max(ref_norm, 1e-30), (what, "norm vs golden", n)
+            if ("g.full." + n) in g:
+                close(gm[n], g["g.full." + n].reshape(gm[n].shape), GRAD_TOL, "golden gradient " + n)
+    print(f"{what}: fp32 training step, worst parameter {rows[0][0]:.2e} ({rows[0][1]}), median {rows[len(rows) // 2][0]:.2e}, "
+          f"d loss / d h_a {ea:.2e}, d loss / d h_t {et:.2e}")
+    return rows
+
+
+@pytest.mark.parametrize("name,d,ne", [("cfg1_train_p0", 128, 4), ("hd96_train_p0", 768, 6)])
+def test_fp32_training_step_vs_golden_gradient_record(H, name, d, ne):
+    g = load_golden(name)
+    _check_step(H, g, g["h_a"], g["h_t"], g["mask_a"], g["mask_t"], d, ne, name)
+
+
+def test_fp32_training_step_cfg2_shape_vs_reference_golden(H):
+    """the headline shape (d=768, T_a=400, T_t=128, N_e=6; B=2, ragged masks): outputs, loss and gradient record of the fixture
+    were generated by importing the reference"""
+    from conftest import cfg2_seeded_inputs
+    g = load_golden("cfg2_seeded")
+    h_a, h_t, m_a, m_t = cfg2_seeded_inputs(g)
+    _check_step(H, g, h_a, h_t, m_a, m_t, 768, 6, "cfg2_seeded")
+
+
+@pytest.mark.parametrize("B,Ta,Tt,kw", [(3, 70, 33, dict(d_model=256, num_emotions=5, n_heads=8)),
+                                        (2, 50, 50, dict(d_model=128, num_emotions=4, n_heads=4, num_layers_fusion=1, num_layers_decoder=3)),
+                                        (2, 90, 20, dict(d_model=1024, num_emotions=7, n_heads=8, num_layers_fusion=1, num_layers_decoder=1))])
+def test_fp32_training_step_default_init_seeded(H, B, Ta, Tt, kw):
+    """default torch initialisation, ragged masks, head_dim 32 / 32 / 128, equal and unequal lengths, other depths"""
+    h_a, h_t, m_a, m_t = _rand_batch(B, Ta, Tt, kw["d_model"], 77 + B)
+    y = (torch.rand(B, kw["num_emotions"], generator=torch.Generator().manual_seed(9)) < 0.3).float()
+    _check_step(H, {"y": y}, h_a, h_t, m_a, m_t, kw["d_model"], kw["num_emotions"], f"seeded {kw}", closed=False, kw=kw)
+
+
+@pytest.mark.parametrize("B,H_,Lq,Lk,hd,masked", [(2, 3, 70, 45, 96, True), (1, 2, 130, 130, 64, False), (3, 8, 6, 50, 16, True),
+                                                  (2, 4, 33, 200, 128, True), (2, 2, 64, 64, 32, False)])
+def test_attention_bwd_f32_against_float64(H, B, H_, Lq, Lk, hd, masked):
+    """hriemo_attn_bwd_f32 (dQ kernel + dK / dV kernel on the fp32 MFMA) against float64 autograd of softmax(QK^T/sqrt(hd)+mask)V"""
+    from hri_emo_amd import _fp32
+    g = torch.Generator().manual_seed(Lq + Lk)
+    d = H_ * hd
+    q = torch.randn(B * Lq, d, generator=g); kv = torch.randn(B * Lk, 2 * d, generator=g); do = torch.randn(B * Lq, d, generator=g)
+    kpm = None
+    if masked:
+        lk = torch.randint(1, Lk + 1, (B,), generator=g)
+        kpm = torch.arange(Lk)[None] >= lk[:, None]
+    q64 = q.double().view(B, Lq, H_, hd).transpose(1, 2).requires_grad_(True)
+    k64 = kv[:, :d].double().view(B, Lk, H_, hd).transpose(1, 2).requires_grad_(True)
+    v64 = kv[:, d:].double().view(B, Lk, H_, hd).transpose(1, 2).requires_grad_(True)
+    s = q64 @ k64.transpose(-1, -2) / math.sqrt(hd)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    o64 = torch.softmax(s, -1) @ v64
+    o64.backward(do.double().view(B, Lq, H_, hd).transpose(1, 2))
+    qc, kvc, doc = q.cuda(), kv.cuda(), do.cuda()
+    k8 = kpm.cuda().view(torch.uint8) if kpm is not None else None
+    o, lse = _fp32.attn(qc, kvc[:, :d], kvc[:, d:], B, H_, Lq, Lk, hd, k8, want_lse=True)
+    dq = torch.empty_like(qc); dkv = torch.empty_like(kvc)
+    _fp32.attn_bwd(qc, kvc[:, :d], kvc[:, d:], o, doc, lse, dq, dkv[:, :d], dkv[:, d:], B, H_, Lq, Lk, hd, k8)
+    back = lambda t, L: t.transpose(1, 2).reshape(B * L, d)          # noqa: E731
+    for got, ref, L, n in ((dq, q64.grad, Lq, "dQ"), (dkv[:, :d], k64.grad, Lk, "dK"), (dkv[:, d:], v64.grad, Lk, "dV")):
+        r = back(ref, L)
+        err = float((got.double().cpu() - r).abs().max() / r.abs().max())
+        assert err <= 2e-5, (n, err)
+    if kpm is not None:
+        pad = kpm.reshape(-1)
+        assert float(dkv.cpu()[pad].abs().max()) == 0.0               # PAD keys receive exactly no gradient
+
+
+def test_backward_row_kernels_f32_against_float64(H):
+    """hriemo_add_ln_bwd_f32, hriemo_colsum_f32 (with and without the ReLU mask), hriemo_split3_f32 forms 2 / 3 and the dX / dW
+    compositions of _fp32.linear_dx / linear_dw against float64"""
+    from hri_emo_amd import _fp32, _ops
+    g = torch.Generator().manual_seed(5)
+    for M, d in ((300, 768), (37, 128), (9, 2048)):
+        G = torch.randn(M, d, generator=g); X = torch.randn(M, d, generator=g); dY = torch.randn(M, d, generator=g)
+        gamma = 1 + 0.1 * torch.randn(d, generator=g)
+        G64, X64, gam64 = G.double().requires_grad_(True), X.double().requires_grad_(True), gamma.double().requires_grad_(True)
+        bet64 = torch.zeros(d, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.layer_norm(G64 + X64, (d,), gam64, bet64, 1e-5).backward(dY.double())
+        ds, dgam, dbet, dbias = _fp32.add_ln_bwd(dY.cuda(), G.cuda(), X.cuda(), gamma.cuda())
+        for got, ref, n in ((ds, G64.grad, "dS"), (dgam, gam64.grad, "dgamma"), (dbet, bet64.grad, "dbeta"), (dbias, G64.grad.sum(0), "dbias")):
+            err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+            assert err <= 2e-5, (M, d, n, err)
+    x = torch.randn(700, 264, generator=g); mk = torch.randn(700, 264, generator=g)
+    assert float((_fp32.colsum(x.cuda()).double().cpu() - x.double().sum(0)).abs().max()) <= 1e-4
+    ref = (x.double() * (mk > 0)).sum(0)
+    assert float((_fp32.colsum(x.cuda(), mask=mk.cuda()).double().cpu() - ref).abs().max()) <= 1e-4
+    # split forms 2 / 3: row-stacked [hi ; mid ; hi] / [hi ; hi ; mid]; forms 6 / 7: the exact three-way split, six stacked blocks
+    xm = x * (mk > 0)
+    hi = xm.bfloat16().float()
+    mid = (xm - hi).bfloat16().float()
+    lo = (xm - hi - mid).bfloat16().float()
+    assert torch.equal(hi + mid + lo, xm)
+    M = x.shape[0]
+    for form in (2, 3):
+        y = _fp32.split(x.cuda(), form, mask=mk.cuda()).float().cpu()
+        assert torch.equal(y[:M], hi) and torch.equal(y[M:2 * M], mid if form == 2 else hi) and torch.equal(y[2 * M:], hi if form == 2 else mid)
+    for form in (6, 7):
+        y = _fp32.split(x.cuda(), form, mask=mk.cuda()).float().cpu()
+        order = (hi, mid, lo, hi, mid, hi) if form == 6 else (hi, hi, hi, mid, mid, lo)
+        assert all(torch.equal(y[j * M:(j + 1) * M], b) for j, b in enumerate(order)), form
+    # dX = dY . W and dW = dY^T . X through the split GEMMs
+    sh = _ops.Shadows()
+    for M, N, K in ((300, 264, 136), (1000, 768, 3072), (40, 8, 2304)):
+        dy = torch.randn(M, N, generator=g); w = torch.nn.Parameter((torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()); xx = torch.randn(M, K, generator=g)
+        dx = _fp32.linear_dx(dy.cuda(), sh, w).double().cpu()
+        r = dy.double() @ w.detach().double().cpu()
+        assert float((dx - r).abs().max() / r.abs().max()) <= 2e-6, ("dX", M, N, K)
+        dw = _fp32.linear_dw(dy.cuda(), xx.cuda()).double().cpu()
+        r = dy.double().t() @ xx.double()
+        assert float((dw - r).abs().max() / r.abs().max()) <= 2e-6, ("dW", M, N, K)
+
+
+def test_mosei_wrapper_training_step_fp32(H):
+    """SURVEY 8(f) rank 1 in the fp32 mode: the odd-K projections (74 / 300 -> d) take part in the backward"""
+    torch.manual_seed(4)
+    kw = dict(d_audio=74, d_text=300, d_model=128, num_emotions=6, n_heads=4, num_layers_fusion=1, num_layers_decoder=1, dropout=0.0)
+    ref = O.MoseiFusionWithEmotionDecoder(**kw).train()
+    m = H.MoseiFusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    g = torch.Generator().manual_seed(6)
+    xa, xt = torch.randn(3, 40, 74, generator=g), torch.randn(3, 24, 300, generator=g)
+    ma = torch.arange(40)[None] >= torch.tensor([40, 31, 17])[:, None]
+    mt = torch.arange(24)[None] >= torch.tensor([24, 9, 20])[:, None]
+    y = (torch.rand(3, 6, generator=g) < 0.4).float()
+    loss_r, logits_r, z_r, ga_r, gt_r, gr = _train_step(ref, xa, xt, ma, mt, y)
+    loss_m, logits_m, z_m, ga_m, gt_m, gm = _train_step(m, cu(xa), cu(xt), cu(ma), cu(mt), cu(y))
+    close(logits_m, logits_r, what="logits")
+    rows = sorted(((_rel(gm[n], gr[n]), n) for n in gr), reverse=True)
+    assert rows[0][0] <= GRAD_TOL, rows[:5]
+    assert _rel(ga_m, ga_r) <= GRAD_TOL and _rel(gt_m, gt_r) <= GRAD_TOL

@@ -400,15 +400,15 @@ def test_add_ln_fwd_bwd(ops, M, d, p, resid):
     assert (dbias.cpu() - Gf.grad.sum(0)).abs().max() <= 2e-2 * max(1.0, Gf.grad.sum(0).abs().max().item())
 
 
-@pytest.mark.parametrize("M,d,p", [(37, 128, 0.1), (1000, 768, 0.1), (64, 768, 0.0), (333, 1024, 0.2), (50, 256, 0.1), (21, 512, 0.1),
-                                   (5, 704, 0.1)])
+@pytest.mark.parametrize("M,d,p", [(37, 128, 0.1), (1000, 768, 0.1), (64, 768, 0.0), (4100, 768, 0.1), (333, 1024, 0.2), (50, 256, 0.1),
+                                   (21, 512, 0.1), (5, 704, 0.1)])
 def test_add_ln_quad_mapped_kernels_equal_the_chunk_mapped_ones(ops, M, d, p):
     """Round 4: LayerNorm(x + dropout(g)) forward / backward on the quad mapping (lane l owns 4-element quads l, l + 64, ...;
     software-pipelined rows, persistent grid; d <= 1024, fp32 twin in and out) against the chunk-mapped kernels on the same
     operands through the C-ABI switch hriemo_rowops_force_variant: the SAME dropout masks (outputs equal to fp32 rounding of
     the two wave sums, dropped elements exactly zero in both), the same column sums, and both against fp32 torch math.
-    Shapes: d = 768 / 1024 / 256 / 512 (every lane owns all its quads), d = 128 and 704 (clamped lanes), M below and above
-    one grid round."""
+    Shapes: d = 768 / 1024 / 256 / 512 (the widths the quad mapping is built for), d = 128 and 704 (not multiples of 256: both
+    settings run the chunk-mapped kernel and must agree bit for bit), M below and above one grid round."""
     from hri_emo_amd import _lib
     g = torch.Generator().manual_seed(11 + M + d)
     G = torch.randn(M, d, generator=g).bfloat16().cuda()
@@ -450,6 +450,9 @@ def test_add_ln_quad_mapped_kernels_equal_the_chunk_mapped_ones(ops, M, d, p):
         assert (a - b).abs().max() <= lim * max(1.0, b.abs().max().item()), (n, float((a - b).abs().max()))
     frac_equal = float((res[0][0] == res[1][0]).float().mean())
     assert frac_equal > 0.99, frac_equal            # bf16 y: the mappings agree bit for bit almost everywhere
+    if d % 256:
+        for n, a, b in zip(names, res[0], res[1]):
+            assert torch.equal(a, b), n
 
 
 def test_rowdot_expand(ops):
