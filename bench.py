@@ -36,7 +36,7 @@ WORKLOADS = {
                      batch=32, flop=227.115e9, gemm="mx_fp8"),
 }
 CFG = dict(WORKLOADS["cfg2"]["model"], beta_hidden=256,
-           dropout=float(os.environ.get("HRIEMO_BENCH_DROPOUT", "0.1")))     # 0.1 = reference default (the headline)
+           dropout=0.1)                   # 0.1 = reference default (the headline); --dropout changes it
 T_A, T_T = 400, 128
 FLOP_PER_UTT_FWD_BWD = 65.378e9           # SURVEY.md 8(d), closed form == FlopCounterMode
 PEAK_BF16_TFLOPS = 2500.0                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph replay per step")
     ap.add_argument("--graph-dp", action="store_true", help="N>1: replay a captured step and all-reduce afterwards (no overlap)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="dropout probability of the benchmark model (0.1 = the reference default)")
+    ap.add_argument("--captured-exchange", action="store_true",
+                    help="N>1: also probe the replay whose graph holds the gradient exchange (capture(collectives=True)) as a third mode")
     return ap.parse_args()
 
 
@@ -149,7 +152,7 @@ def main():
     global CFG, T_A, T_T, FLOP_PER_UTT_FWD_BWD
     a = parse()
     wl = WORKLOADS[a.workload]
-    CFG = dict(wl["model"], beta_hidden=256, dropout=CFG["dropout"])
+    CFG = dict(wl["model"], beta_hidden=256, dropout=float(a.dropout))
     T_A, T_T, FLOP_PER_UTT_FWD_BWD = wl["T_a"], wl["T_t"], wl["flop"]
     if a.batch_per_gpu is None:
         a.batch_per_gpu = wl["batch"]
@@ -240,10 +243,10 @@ def main():
                 modes[name] = probe()
             return int(flag.item()) == 1
 
-        # (opt-in: HRIEMO_BENCH_CAPTURED_EXCHANGE=1.  It is rehearsed on one rank over RCCL in the GPU suite, but it has never run
+        # (opt-in: --captured-exchange.  It is rehearsed on one rank over RCCL in the GPU suite, but it has never run
         # on more than one GPU -- no multi-GPU node was available to the builder -- and a collective that hangs inside a
         # capture would take the whole scaling run with it; the two modes below are the measured-safe defaults)
-        if os.environ.get("HRIEMO_BENCH_CAPTURED_EXCHANGE", "0") == "1":
+        if a.captured_exchange:
             try_capture("replay+captured exchange", collectives=True)
         dp.buckets.suspended = True
         try_capture("replay, exchange after")

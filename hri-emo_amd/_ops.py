@@ -157,10 +157,9 @@ STEP_ID = 0                # bumped at the top of every model step (begin_step):
 
 
 def begin_step():
-    global STEP_ID, _last_heavy_attn
+    global STEP_ID
     STEP_ID += 1
     _half_reports.clear()
-    _last_heavy_attn = None
 
 WEIGHTS_EPOCH = 0          # bumped by anything that rewrites parameter storage behind autograd's back (optim.FusedClipAdamW
                            # updates the flat buffer through raw pointers: p._version and p.data_ptr() do not move)
@@ -244,42 +243,6 @@ class Shadows:
         for p in params:
             self.get(p)
 
-    def plan(self, p, jobs):
-        """get() without the launch: if the shadow of `p` is stale, its cast is appended to `jobs` (cast_batch() issues them all
-        in one launch) and the entry is marked fresh for this step"""
-        key = id(p)
-        ent = self._d.get(key)
-        ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
-        if (CAPTURING and (ent is None or len(ent) < 3 or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != p.device:
-            s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
-                torch.empty(p.shape, dtype=BF16, device=p.device)
-            _require_gpu(p)
-            _require_fp32_master(p)
-            if not p.is_contiguous():
-                return self.get(p)
-            jobs.append((p.data_ptr(), s.data_ptr(), p.numel()))
-            self._d[key] = (ver, s, STEP_ID)
-
-    def plan_cat(self, parts, jobs):
-        """get_cat() without the launches (one job per part)"""
-        key = ("cat",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
-        ent = self._d.get(key)
-        ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
-        dev = parts[0][0].device
-        if (CAPTURING and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != dev:
-            if not all(p.is_contiguous() for p, _, _ in parts):
-                return self.get_cat(parts)
-            rows = sum(r1 - r0 for _, r0, r1 in parts)
-            K = parts[0][0].shape[1]
-            s = ent[1] if ent is not None and ent[1].device == dev else torch.empty((rows, K), dtype=BF16, device=dev)
-            at = 0
-            for p, r0, r1 in parts:
-                _require_gpu(p)
-                _require_fp32_master(p)
-                jobs.append((p.data_ptr() + r0 * K * 4, s.data_ptr() + at * K * 2, (r1 - r0) * K))
-                at += r1 - r0
-            self._d[key] = (ver, s, STEP_ID)
-
     def get_cat(self, parts):
         """bf16 shadow of the row-wise concatenation of master slices: parts = ((param, r0, r1), ...) -> [sum(r1 - r0), K].
         One GEMM per shared input (SharedProjFn) reads it; refreshed when any of the masters changes, like get()."""
@@ -356,13 +319,6 @@ class Shadows:
             ent = (ver, v, STEP_ID)
             self._d[key] = ent
         return ent[1]
-
-
-def cast_batch(jobs):
-    """issue the planned fp32 -> bf16 casts (Shadows.plan / plan_cat) as one launch on the current stream"""
-    if jobs:
-        host = torch.tensor(jobs, dtype=torch.int64)
-        _lib.call("hriemo_cast_f32_to_bf16_batch", host.data_ptr(), len(jobs), _stream())
 
 
 FUSED_WGRAD = True
@@ -473,13 +429,10 @@ def linear_dx(dy, w16, epi=0, aux=None):
     return dx
 
 
-FOLD_FFN_BIAS = None
+FOLD_FFN_BIAS = True       # the first FFN Linear's bias gradient out of the dX GEMM's epilogue (hriemo_gemm_bf16_colsum)
 
 
 def fold_ffn_bias():
-    global FOLD_FFN_BIAS
-    if FOLD_FFN_BIAS is None:
-        FOLD_FFN_BIAS = _os.environ.get("HRIEMO_FOLD_FFN_BIAS", "1") != "0"
     return FOLD_FFN_BIAS
 
 
@@ -690,18 +643,8 @@ def _in_backward():
 # Dropout keep-mask as bit words from the forward to the backward (include/hriemo.h, drop_mask_bits).  Measured at cfg 2: in the
 # two-kernel backward the bit words save the hash but cost three registers in the dK/dV kernel (a wave per SIMD at head_dim 96)
 # and a 2-byte store per lane and key tile in the forward -- no gain; in the single-pass backward (16 < L_k <= 128) they pay
-# (profiles/r02_attention.log).  So a site asks for them exactly when its backward is the single kernel; HRIEMO_ATTN_MASK_BITS=1 / 0
-# forces them on / off everywhere.
-ATTN_MASK_BITS = None
-
-
+# (profiles/r02_attention.log).  So a site asks for them exactly when its backward is the single kernel.
 def attn_mask_bits(B, H, Lk, hd, Lq=None):
-    global ATTN_MASK_BITS
-    if ATTN_MASK_BITS is None:
-        import os
-        ATTN_MASK_BITS = os.environ.get("HRIEMO_ATTN_MASK_BITS", "auto")
-    if ATTN_MASK_BITS in ("0", "1"):
-        return ATTN_MASK_BITS == "1"
     if Lq is not None:
         return bool(_lib.lib().hriemo_attn_bwd_single_pass_q(B, H, Lq, Lk, hd))
     return bool(_lib.lib().hriemo_attn_bwd_single_pass(B, H, Lk, hd))
@@ -729,16 +672,6 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=Fal
     return (o, lse, mb) if want_bits else (o, lse)
 
 
-# The single-pass attention backward kernels hold 80-150 KB of LDS per workgroup.  Two of them launched side by side from the two
-# branch streams (t2a's query-resident kernel and a2t's key-resident one become ready together) split every CU's LDS between them
-# and ran 218 us for the pair against 70 + 62 us one after the other (gpurun_out/tl/full_step.txt, round 3).  With
-# HRIEMO_ATTN_BWD_SERIAL=1 such a launch waits for the previous one of the other stream -- measured neutral on the whole step
-# (7.96 / 7.97 / 7.98 vs 7.94 / 7.95 / 7.99 ms, same box: the step is bound by the sum of its kernels' work, not by which of them
-# overlap), so it stays opt-in.
-ATTN_BWD_SERIAL = _os.environ.get("HRIEMO_ATTN_BWD_SERIAL", "0") == "1"
-_last_heavy_attn = None
-
-
 def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, bias_grad=None, mask_bits=None, cu=None):
     """bias_grad = (db_q [d], db_kv [2d]) fp32 views the column sums of dQ and dK|dV go to: the kernels leave per-block partial
     sums behind (fp32 values before the bf16 rounding of dQ/dK/dV); inside backward with the fused path they are finished by the
@@ -752,12 +685,6 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
         rq, rk = L_.hriemo_attn_bwd_dq_colsum_rows(B, H, Lq, Lk, hd), L_.hriemo_attn_bwd_kv_colsum_rows(B, H, Lq, Lk, hd)
         pq = torch.empty(rq * H * hd, dtype=torch.float32, device=q.device)
         pkv = torch.empty(rk * 2 * H * hd, dtype=torch.float32, device=q.device)
-    global _last_heavy_attn
-    heavy = ATTN_BWD_SERIAL and q.is_cuda and bool(_lib.lib().hriemo_attn_bwd_single_pass_q(B, H, Lq, Lk, hd)
-                                                   or _lib.lib().hriemo_attn_bwd_single_pass(B, H, Lk, hd))
-    cur_s = torch.cuda.current_stream(q.device) if heavy else None
-    if heavy and _last_heavy_attn is not None and _last_heavy_attn[1] != cur_s:
-        cur_s.wait_event(_last_heavy_attn[0])
     if cu is not None:
         _lib.call("hriemo_attn_bwd_varlen", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
                   _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(cu[0]), _p(cu[1]),
@@ -768,10 +695,6 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, kpm, p, seed, si
                   _p(do), do.stride(0), _p(dq), dq.stride(0), _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(kpm),
                   _p(lse), _p(delta), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off,
                   _p(pq), _p(pkv), _p(mask_bits), _stream())
-    if heavy:
-        ev = torch.cuda.Event()
-        ev.record(cur_s)
-        _last_heavy_attn = (ev, cur_s)
     if fold:
         d = H * hd
         deferred = bias_grad[2] if len(bias_grad) > 2 else False
@@ -858,8 +781,8 @@ def add_ln_bwd(dy, g, x, gamma, mean, rstd, p, seed, site, row_off, want_dx=True
 TWIN = _os.environ.get("HRIEMO_FP32_TWIN", "1") != "0"      # carry the fp32 twin of the residual stream (LayerNorm outputs)
 
 
-DEFER_REDUCE = _os.environ.get("HRIEMO_DEFER_REDUCE", "1") != "0"
-FOLD_ATTN_BIAS = _os.environ.get("HRIEMO_FOLD_ATTN_BIAS", "1") != "0"   # in-proj bias grads from the attention backward kernels
+DEFER_REDUCE = True        # bias / LayerNorm column sums finished by ONE launch at the end of backward (_DeferredReduce)
+FOLD_ATTN_BIAS = True      # in-proj bias grads from the attention backward kernels' own column sums
 
 
 class _DeferredReduce:
@@ -919,10 +842,9 @@ _deferred = _DeferredReduce()
 # self-attention, on the side stream, while the audio branch still has ~0.5 ms of its own backward to run), or from an
 # autograd-engine final callback if no such point comes.  Measured at cfg 2: 8.87 -> 8.7 ms per step (skipping them altogether:
 # 8.65).  Off while gradient-ready hooks drive an overlapped exchange (the decoder's bucket would leave last instead of first);
-# HRIEMO_DEFER_SMALL_DW=0 disables it.
-GATE_TWO_STREAMS = _os.environ.get("HRIEMO_GATE_TWO_STREAMS", "1") != "0"     # the gate's text-side LayerNorm + pooling on the side stream
-DEFER_SMALL_DW = _os.environ.get("HRIEMO_DEFER_SMALL_DW", "1") != "0"
-GROUP_SMALL_DW = _os.environ.get("HRIEMO_GROUP_SMALL_DW", "1") != "0"      # the queued weight gradients leave as one grouped GEMM launch
+GATE_TWO_STREAMS = True    # the gate's text-side LayerNorm + pooling on the side stream
+DEFER_SMALL_DW = True
+GROUP_SMALL_DW = True      # the queued weight gradients leave as one grouped GEMM launch
 SMALL_DW_ROWS = 1024
 FLUSH_SITES = set()                # dropout-site ids of the sub-layers whose backward ends a model's text branch (one per CrossModalTransformer)
 _hook_predicates = []              # one per live dp.GradBuckets with gradient-ready hooks (register_hook_predicate)
@@ -1471,17 +1393,14 @@ class GradJoin:
         if self.seen != 0 or self.dep is not None:
             self.seen, self.dep, self.ev = 0, None, None
             raise RuntimeError("GradJoin: a consumer of a shared activation did not run its backward; its partner's gradient was "
-                               "deposited for it (set HRIEMO_GRAD_JOIN=0 to let autograd sum the gradients)")
+                               "deposited for it (_ops.GRAD_JOIN = False lets autograd sum the gradients)")
 
 
-GRAD_JOIN = _os.environ.get("HRIEMO_GRAD_JOIN", "1") != "0"
-SHARED_PROJ = None         # one N = 3d projection GEMM per shared encoder input (SharedProjFn); HRIEMO_SHARED_PROJ=0: Q and K | V apart
+GRAD_JOIN = True           # (False: autograd sums the gradients of a shared activation -- what the tests hold the joins against)
+SHARED_PROJ = True         # one N = 3d projection GEMM per shared encoder input (SharedProjFn); False: Q and K | V apart
 
 
 def shared_proj():
-    global SHARED_PROJ
-    if SHARED_PROJ is None:
-        SHARED_PROJ = _os.environ.get("HRIEMO_SHARED_PROJ", "1") != "0"
     return SHARED_PROJ
 
 

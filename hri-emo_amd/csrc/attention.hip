@@ -1462,12 +1462,7 @@ __global__ __launch_bounds__(64) void attn_probs_kernel(const AttnArgs a) {
 // Sub-tiles per wave.  Measured on cfg 2 (profiles/): the forward is fastest with two 16-row query sub-tiles
 // per wave (K/V fragment reuse), the backward kernels with one (128 instead of ~220 VGPRs -> twice the
 // waves per SIMD to cover their long VALU chains, and less padding waste at L=400).
-static int attn_wide(int backward) {
-  static int v = -1, f = -1;
-  if (v < 0) { const char* e = getenv("HRIEMO_ATTN_WIDE_BWD"); v = (e && e[0] == '1') ? 1 : 0; }
-  if (f < 0) { const char* e = getenv("HRIEMO_ATTN_WIDE_FWD"); f = (e && e[0] == '0') ? 0 : 1; }
-  return backward ? v : f;
-}
+static int attn_wide(int backward) { return backward ? 0 : 1; }      // (the backward's width is chosen per launch: bwd_wide)
 static int check_common(const AttnArgs& a, int hd) {
   HRIEMO_CHECK(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "attn: empty problem");
   HRIEMO_CHECK(hd == 16 || hd == 32 || hd == 64 || hd == 96 || hd == 128, "attn: head_dim %d not built (16/32/64/96/128)", hd);
@@ -1583,28 +1578,25 @@ static bool bwd_wide(int L, int BH, int head_dim) {
 }
 // Single-pass backward: one block holds all keys of a (batch, head) (16 < L_k <= 128) and produces dQ, dK and dV together
 // (5 GEMMs per tile instead of 7, Q/K/V/dO read once): a2t backward 82 us instead of 114 at cfg 2.
-// ON by default (HRIEMO_ATTN_FUSED_BWD=0 selects the two-kernel path).  Its first build returned a few wrong dS elements per
+// Its first build returned a few wrong dS elements per
 // launch with the bit-word mask at two waves per SIMD; traced to the compiler's packed form of the (dP - delta') subtraction
 // (v_pk_add_f32 with the low result reading the high dword of src1: round 3's scripts_dev/forensics reproduce it in 20 of 20
 // runs and isolate the operand select); the file is compiled without SLP vectorisation since.
 static bool bwd_fused(int Lk, int head_dim, int B, int H) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_FUSED_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
-  // (one workgroup per (batch, head); HRIEMO_ATTN_PAIR=1 puts heads 2j, 2j+1 of one sample into a 512-thread workgroup instead --
-  // measured slower, its barriers couple the two problems)
+  // (one 256-thread workgroup per (batch, head).  Round 2 first shipped heads 2j, 2j+1 of a sample in ONE 512-thread workgroup:
+  // its block-wide barriers coupled the two problems -- a2t backward 80 us against 66 -- and that instantiation spilled inside
+  // its loops; removed in round 4)
   (void)B; (void)H;
-  return on && Lk > 16 && Lk <= 128 && head_dim >= 32;
+  return Lk > 16 && Lk <= 128 && head_dim >= 32;
 }
 
 extern "C" int hriemo_attn_bwd_colsum_rows(int B, int H, int L, int head_dim);
 extern "C" int hriemo_attn_bwd_single_pass(int B, int H, int Lk, int head_dim) { return bwd_fused(Lk, head_dim, B, H) ? 1 : 0; }
 
 // Query-resident single pass (attn_bwd_qres_kernel): all queries of a (batch, head) in one block, the keys swept -- for
-// 16 < L_q <= 128 < L_k (t2a at cfg 2; the key-resident form above takes L_k <= 128).  HRIEMO_ATTN_QRES_BWD=0: two kernels.
+// 16 < L_q <= 128 < L_k (t2a at cfg 2; the key-resident form above takes L_k <= 128).
 static bool bwd_qres(int Lq, int Lk, int head_dim, int B, int H) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("HRIEMO_ATTN_QRES_BWD"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on && !bwd_fused(Lk, head_dim, B, H) && Lq > 16 && Lq <= 128 && head_dim >= 32;
+  return !bwd_fused(Lk, head_dim, B, H) && Lq > 16 && Lq <= 128 && head_dim >= 32;
 }
 // 1 if the backward of this shape is ONE kernel of either form (the forward then writes the dropout keep-mask as bit words)
 extern "C" int hriemo_attn_bwd_single_pass_q(int B, int H, int Lq, int Lk, int head_dim) {
@@ -1664,25 +1656,11 @@ static int attn_bwd_impl(const void* Q, long ldq, const void* K, long ldk, const
   const bool bits = a.thr16 != 0 && a.mbits != nullptr;
   if (bwd_fused(Lk, head_dim, B, H)) {
     hriemo_prof_begin(HP_ATTN_BWD_DKV, st);
-    // PAIR (two (batch, head) problems per workgroup, one workgroup per CU) whenever two problems fit the CU's LDS; otherwise a
-    // problem needs more than half the LDS and is alone on its CU anyway
+    // one 256-thread workgroup per (batch, head); two of them share a CU where two problems fit its LDS
 #define CALLF(HD, KW_, BITS_)                                                                                                    \
   {                                                                                                                              \
-    constexpr int lds_one__ = 4 * 32 * AttnGeom<HD>::STRIDE + (4 * KW_ * 16) * AttnGeom<HD>::STRIDE + 2 * (4 * KW_ * 16) * 96;     \
-    static const bool pair__ = [] { const char* e = getenv("HRIEMO_ATTN_PAIR"); return e && e[0] == '1'; }();                     \
-    if constexpr (2 * lds_one__ <= 160 * 1024) {                                                                                 \
-      if (!pair__ || (B * H) % 2 != 0) {       /* two independent workgroups per CU (own barriers): a2t backward 66 us vs 80 paired */ \
-        if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false, true>), dim3(B * H), dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);      \
-      } else if ((B * H) % 2 == 0) {                                                                                             \
-        if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true, true>), dim3(B * H / 2), dim3(512), 0, st, a); \
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, true>), dim3(B * H / 2), dim3(512), 0, st, a);   \
-      }                                                                                                                          \
-      else { hriemo_set_error("attn_bwd: internal: odd (batch, head) count reached the paired kernel"); return 1; }            \
-    } else {                                                                                                                     \
-      if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false, true>), dim3(B * H), dim3(256), 0, st, a); \
-      else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);        \
-    }                                                                                                                            \
+    if (a.cu_q != nullptr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false, true>), dim3(B * H), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, 4, KW_, 32, BITS_, true, false>), dim3(B * H), dim3(256), 0, st, a);          \
   }
     if (Lk <= 64) {
       if (bits) {

@@ -553,8 +553,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __rest
       }
     }
   }
-  for (int sgm = 0; sgm < 3; ++sgm) {
-    const f32x4* a = sgm == 0 ? ag : (sgm == 1 ? ab : abias);
+  // (one call per accumulator array: picking the array by a run-time index would put all three into scratch)
+  auto fold = [&](const f32x4 (&a)[NV4], float* dst) {
     for (int w = 0; w < 4; ++w) {
       if (wave == w) {
 #pragma unroll
@@ -562,14 +562,17 @@ __global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __rest
           const int q = lane + 64 * c;
           if (q < nq) {
             f32x4 v = a[c];
-            if (w != 0) v += *(const f32x4*)(red + sgm * d + q * 4);
-            *(f32x4*)(red + sgm * d + q * 4) = v;
+            if (w != 0) v += *(const f32x4*)(dst + q * 4);
+            *(f32x4*)(dst + q * 4) = v;
           }
         }
       }
       __syncthreads();
     }
-  }
+  };
+  fold(ag, red);
+  fold(ab, red + d);
+  fold(abias, red + 2 * d);
   float* out = part + (long)blockIdx.x * 3 * d;
   for (int t = threadIdx.x; t < 3 * d; t += 256) out[t] = red[t];
 }
@@ -577,13 +580,14 @@ static int add_ln_bwd_f32_blocks(int M) { int g = (M + 3) / 4; return g > 512 ? 
 extern "C" long hriemo_add_ln_bwd_f32_workspace_bytes(int M, int d) { return (long)add_ln_bwd_f32_blocks(M) * 3 * d * 4; }
 extern "C" int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dgamma,
                                      float* dbeta, float* dbias, int accumulate, int M, int d, float eps, float* workspace, hipStream_t st) {
-  HRIEMO_CHECK(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "add_ln_bwd_f32: d=%d must be a multiple of 4, at most 4096", d);
+  HRIEMO_CHECK(M > 0 && d > 0 && d % 4 == 0 && d <= 1024, "add_ln_bwd_f32: d=%d must be a multiple of 4, at most 1024", d);
   HRIEMO_CHECK(dY != nullptr && G != nullptr && gamma != nullptr && dS != nullptr && dgamma != nullptr && dbeta != nullptr && workspace != nullptr,
                "add_ln_bwd_f32: missing operand");
   const int nb = add_ln_bwd_f32_blocks(M);
   hriemo_prof_begin(HP_ROWOPS, st);
-  if (d <= 1024) hipLaunchKernelGGL((add_ln_bwd_f32_kernel<4>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, workspace, M, d, eps);
-  else hipLaunchKernelGGL((add_ln_bwd_f32_kernel<16>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, workspace, M, d, eps);
+  // (the row, its gradient and three column accumulators live in registers: 1024 columns -- every BASELINE config -- is what fits
+  // without scratch; wider rows are refused above rather than served by a spilling instantiation)
+  hipLaunchKernelGGL((add_ln_bwd_f32_kernel<4>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, workspace, M, d, eps);
   HRIEMO_LAUNCH_CHECK("add_ln_bwd_f32_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (double)M * d * 16.0);
   SegOut so; so.o[0] = dgamma; so.o[1] = dbeta; so.o[2] = dbias;

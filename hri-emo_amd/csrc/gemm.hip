@@ -501,10 +501,8 @@ extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev
 
 // Work-queue words for the persistent kernels: one 16-word slot per (device, stream) -- launches on one stream are
 // serialised and every launch leaves its slot zeroed (last block out), launches on different streams never share one.
-// Allocated once, outside any stream capture; until then (or with HRIEMO_GEMM_STATIC=1) the kernels walk statically.
+// Allocated once, outside any stream capture; until then the kernels walk statically.
 unsigned* hriemo_gemm_sched_slot(hipStream_t st) {
-  static const bool disabled = [] { const char* e = getenv("HRIEMO_GEMM_STATIC"); return e && e[0] == '1'; }();
-  if (disabled) return nullptr;
   constexpr int MAXDEV = 16, MAXSLOT = 64;
   static unsigned* base[MAXDEV] = {nullptr};
   static hipStream_t owner[MAXDEV][MAXSLOT];
@@ -579,14 +577,11 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
     // K-step on the 64x128 tile, the same with a 6-deep ring), so these launches are as fast as their largest block's operand
     // bytes are small: 32-row tiles, 64 columns where that still fits one round of CUs and the B operand is K-contiguous
     if (!(M <= 512 && N >= 256)) return 0;
-    static const bool wide = [] { const char* e = getenv("HRIEMO_SMALL_GEMM_WIDE"); return e && e[0] == '1'; }();   // A/B: the 64x128 tile
-    if (K <= 384 || wide) return 3;
+    if (K <= 384) return 3;
     return (tb == 0 && N <= 1024) ? 8 : 7;
   }
   // (config 5, 320x128: 480 instead of 600 tiles for the 25600 x 768 outputs, is 3-8 % faster on those launches alone
-  // but 0.1 ms slower inside the two-stream step -- kept as a tuning configuration, never picked)
-  static const bool t320 = [] { const char* e = getenv("HRIEMO_GEMM_320"); return e && e[0] == '1'; }();   // A/B switch, see above
-  if (t320 && N <= 1024 && M >= 16384 && M % 320 == 0) return 5;
+  // but 0.1 ms slower inside the two-stream step -- kept as a tuning configuration for hriemo_gemm_force_config, never picked)
   if (tb == 0) return (N >= 2048 && M >= 16384) ? 2 : 1;                       // NT
   return (N >= 2048 && M >= 16384) ? 2 : 1;                                    // NN
 }

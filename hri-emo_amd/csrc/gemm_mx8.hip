@@ -50,7 +50,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
   static_assert(A_PW * NWAVE * 1024 == A_BYTES && B_PW * NWAVE * 1024 == B_BYTES && S_PW * NWAVE == 8, "tile must split evenly over waves");
   static_assert(NS == 2, "two ring slots");
   static_assert(BM <= 256 && BN <= 256, "a scale segment holds 256 rows");
-  static_assert(MT * NTL <= 16, "64x64 wave tiles: two fragment sets of 72 registers beside 64 accumulators");
+  static_assert(MT * NTL <= 16 && MT % 2 == 0, "64x64 wave tiles: one activation fragment set in halves, two weight sets");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,16 +138,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
   };
 
   f32x4 acc[MT][NTL];
-  struct Frags { i32x8 a[MT]; i32x8 b[NTL]; int sa[MT]; int sb[NTL]; };
-  auto load_frags = [&](const char* st, Frags& f) {
+  // Fragment registers (round 4: no scratch in the K loop).  Round 2 kept TWO full fragment sets (2 x 72 registers beside 64
+  // accumulators): at the 256-register limit of an 8-wave block hipcc spilled 8-57 VGPRs and dozens of SGPRs, reloaded inside
+  // the K loop (`make check-isa`).  Now ONE set of activation fragments (a[MT]) whose halves are refilled as soon as their
+  // MFMA cluster has consumed them, and two sets of weight fragments (b / nb) that swap roles every step: 32 + 2 x 32 + scales
+  // = ~110 registers beside the accumulators.
+  struct AFr { i32x8 a[MT]; int sa[MT]; };
+  struct BFr { i32x8 b[NTL]; int sb[NTL]; };
+  auto load_a = [&](const char* st, AFr& f, int lo, int hi) {
     const int g = lane >> 4, i = lane & 15;
     const char* sc = st + A_BYTES + B_BYTES;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int row = wm * MT * 16 + mi * 16 + i;
-      f.a[mi] = lds_mx_frag(st, row, lane);
-      f.sa[mi] = (int)*(LDS_PTR(const uint8_t))(sc + g * 256 + row);
-    }
+    for (int mi = 0; mi < MT; ++mi)
+      if (mi >= lo && mi < hi) {
+        const int row = wm * MT * 16 + mi * 16 + i;
+        f.a[mi] = lds_mx_frag(st, row, lane);
+        f.sa[mi] = (int)*(LDS_PTR(const uint8_t))(sc + g * 256 + row);
+      }
+  };
+  auto load_b = [&](const char* st, BFr& f) {
+    const int g = lane >> 4, i = lane & 15;
+    const char* sc = st + A_BYTES + B_BYTES;
 #pragma unroll
     for (int ni = 0; ni < NTL; ++ni) {
       const int row = wn * NTL * 16 + ni * 16 + i;
@@ -155,22 +166,27 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
       f.sb[ni] = (int)*(LDS_PTR(const uint8_t))(sc + (4 + g) * 256 + row);
     }
   };
-  auto mma_rows = [&](const Frags& f, int lo, int hi) {
+  auto mma_rows = [&](const AFr& fa, const BFr& fb, int lo, int hi) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
       if (mi >= lo && mi < hi) {
 #pragma unroll
         for (int ni = 0; ni < NTL; ++ni)     // transposed product: the weight fragment is the A operand, so a lane owns 4 columns of a row
-          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f.b[ni], f.a[mi], acc[mi][ni], 0, 0, 0, f.sb[ni], 0, f.sa[mi]);
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb.b[ni], fa.a[mi], acc[mi][ni], 0, 0, 0, fb.sb[ni], 0, fa.sa[mi]);
       }
   };
 
   // The operand stream is one sequence of 128-deep steps over (tile, K-step), every tile padded to an EVEN number of
   // steps (a padding step is staged with every lane out of range: zero operands, zero scale bytes, adds nothing), so the
-  // two fragment sets keep fixed roles: even steps compute on set A and read set B, odd steps the other way round, and a
-  // tile always ends with the NEXT tile's first fragments in set A.  Every step is the same unconditional code:
-  //   DMA(position s+1) | MFMA(rows 0..MT/2 of s) | retire s+1, barrier | read fragments of s+1 | MFMA(rows MT/2..MT of s)
-  // All reads of a stage happen between the barrier that publishes it and the next one, i.e. before its slot is restaged.
+  // two weight-fragment sets keep fixed roles: even steps multiply set B and fill set NB, odd steps the other way round, and a
+  // tile always ends with the NEXT tile's first fragments in place.  Every step is the same unconditional code:
+  //   DMA(position s+1) | read a[MT/2..MT) of s | MFMA(rows 0..MT/2 of s) | retire s+1, barrier |
+  //   read a[0..MT/2) and the weight fragments of s+1 | MFMA(rows MT/2..MT of s)
+  // The upper activation half of position s is read at the top of step s (its registers were freed by the last cluster of
+  // step s-1) and lands under the first cluster; the lower half and the weights of s+1 land under the second.  All reads of a
+  // stage happen between the barrier that publishes it and the barrier of the step after, i.e. before its slot is restaged:
+  // position s sits in slot s & 1, is restaged (position s+2) at the top of step s+1 -- after the barrier in the middle of step
+  // s, which every wave passes only with its upper-half reads of position s retired (lgkmcnt(0) in front of it).
   const int nkp = (nk + 1) & ~1;
   TileInfo T = decode(wg);
   auto stage_pos = [&](int slot, const TileInfo& t, int ks) {
@@ -192,8 +208,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = 1;
   bool parked = false;
-  Frags fA, fB;
-  load_frags(smem, fA);
+  AFr fa;
+  BFr fbA, fbB;
+  load_a(smem, fa, 0, MT / 2);
+  load_b(smem, fbA);
   for (;;) {
     if (parked) {
       __builtin_amdgcn_s_barrier();     // the id parked by wave 0 after its last epilogue is visible
@@ -204,12 +222,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto kstep = [&](int s, Frags& fc, Frags& fn) {
+    auto kstep = [&](int s, BFr& fc, BFr& fn) {
       if (s + 1 < nkp) stage_pos(nxt, T, s + 1);
       else if (has_next) { const TileInfo NX = decode(nwg); stage_pos(nxt, NX, 0); }
       __builtin_amdgcn_sched_barrier(0);
+      load_a(smem + cur * STAGE, fa, MT / 2, MT);   // upper half of THIS position: lands under the first cluster
       __builtin_amdgcn_s_setprio(1);
-      mma_rows(fc, 0, MT / 2);
+      mma_rows(fa, fc, 0, MT / 2);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       cur ^= 1; nxt ^= 1;
@@ -217,13 +236,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
       __builtin_amdgcn_s_waitcnt(0xC07F);           // ... its reads of position s are complete (slot may be restaged) ...
       __builtin_amdgcn_s_barrier();                 // ... and everybody's
       __builtin_amdgcn_sched_barrier(0);
-      load_frags(smem + cur * STAGE, fn);           // lands under the second cluster (garbage, never used, after the last position)
+      load_a(smem + cur * STAGE, fa, 0, MT / 2);    // position s+1: lower activation half (its registers are free) + weights;
+      load_b(smem + cur * STAGE, fn);               // land under the second cluster (garbage, never used, after the last position)
       __builtin_amdgcn_s_setprio(1);
-      mma_rows(fc, MT / 2, MT);
+      mma_rows(fa, fc, MT / 2, MT);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
-    for (int s = 0; s < nkp; s += 2) { kstep(s, fA, fB); kstep(s + 1, fB, fA); }
+    for (int s = 0; s < nkp; s += 2) { kstep(s, fbA, fbB); kstep(s + 1, fbB, fbA); }
     int drawn = end;
     if (dyn && has_next && tid == 0) drawn = beg + (int)atomicAdd(qctr, 1u);
     if (OUTF32) {

@@ -951,11 +951,6 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
 }
 
 // ================================================================== host entry points
-static bool lnpool_prefetch() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("HRIEMO_LNPOOL_PREFETCH"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on != 0;
-}
 #define DISPATCH_NCH(d, CALL)                         \
   {                                                   \
     const int nch__ = ((d) / 8 + 63) / 64;            \
@@ -965,11 +960,18 @@ static bool lnpool_prefetch() {
     else { CALL(8); }                                 \
   }
 
-// quad-mapped add_ln kernels (round 4) for d <= 1024 without the MX copy; hriemo_rowops_force_variant(1) keeps the chunk mapping
-// everywhere (A/B measurements, and the tests that hold the two mappings against each other)
-static int g_rowops_variant = 0;
+// Which add_ln kernels run: 1 (default) the chunk-mapped ones, 0 the quad-mapped, software-pipelined ones of round 4 (d = 256 k).
+// Measured alone on the cfg-2 shapes (scripts_dev/bench_rows.py, profiles/r04_rows.log): forward 38.6 -> 36.8 us (audio rows),
+// 16.0 -> 14.8 us (text rows), backward 19.1 -> 17.7 us (text), audio backward unchanged -- both mappings already move 5.5-6.4
+// TB/s alone, i.e. what HBM3E gives; ~0.03 ms of an 8 ms step.  The two mappings draw the same dropout masks and differ by the
+// summation order of the row statistics only, but that is enough to change a bf16 rounding of y in a few elements per
+// thousand, and on the ill-conditioned closed-form fixtures such a perturbation moves the per-parameter gradient errors by
+// 2-4 % of themselves (both mappings are equally far from the fp32 oracle: scripts_dev/diag_grads_variant2.py) -- enough to
+// push two parameters over bounds that were calibrated on the chunk mapping's draw.  The chunk mapping therefore stays the
+// numerics of record; the quad kernels are built, tested against it (tests/test_gpu_kernels.py) and selectable here.
+static int g_rowops_variant = 1;
 extern "C" int hriemo_rowops_force_variant(int v) {
-  g_rowops_variant = v == 1 ? 1 : 0;
+  g_rowops_variant = v == 0 ? 0 : 1;
   return 0;
 }
 static bool use_quad(int d) { return g_rowops_variant == 0 && d <= 1024 && d % 256 == 0; }
@@ -1496,9 +1498,9 @@ extern "C" int hriemo_ln_pool_fwd(const void* X, const float* X32, const unsigne
   HRIEMO_CHECK(Lkeep >= 0 && Lkeep <= L, "ln_pool_fwd: Lkeep=%d out of range (L=%d)", Lkeep, L);
   const int nc = (L + 31) / 32;
   hriemo_prof_begin(HP_ROWOPS, st);
-  // (next-row prefetch for d <= 1024, where it fits the registers: HRIEMO_LNPOOL_PREFETCH=0 switches it off)
+  // (next-row prefetch for d <= 1024, where it fits the registers)
 #define CALL(N)                                                                                                                  \
-  if ((N) <= 2 && lnpool_prefetch())                                                                                             \
+  if ((N) <= 2)                                                                                                                  \
     hipLaunchKernelGGL((ln_pool_fwd_kernel<N, ((N) <= 2)>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, X32, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps); \
   else                                                                                                                           \
     hipLaunchKernelGGL((ln_pool_fwd_kernel<N, false>), dim3(nc, B), dim3(256), d * 4, st, (const bf16_t*)X, X32, mask, gamma, beta, (bf16_t*)Yn, mean, rstd, partials, L, Lkeep, d, eps)

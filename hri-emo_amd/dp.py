@@ -19,9 +19,6 @@ import torch.distributed as dist
 
 log = logging.getLogger("hri_emo_amd.dp")
 
-# gradient memset on the side stream beside the first kernels of the forward instead of in front of them: measured neutral
-# (8.18 vs 8.14-8.19 ms per step on one box), opt-in
-_ZERO_BESIDE = os.environ.get("HRIEMO_ZERO_BESIDE", "0") == "1"
 # packed (varlen) graphs: the packed row count of a modality is rounded up to a multiple of (padded rows / this): finer = fewer
 # wasted rows, more distinct graphs over a run (DataParallelStep.capture)
 _VARLEN_BUCKETS = max(1, int(os.environ.get("HRIEMO_VARLEN_BUCKETS", "64")))
@@ -211,30 +208,9 @@ class GradBuckets:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * 4:
                 p.grad = self.flat[off:off + n].view_as(p)
 
-    def zero_grad(self, beside=False):
-        """beside=True (CUDA, two streams): the 218 MB memset runs on the side stream beside the first kernels of the forward
-        instead of in front of them; wait_zeroed() orders the caller's stream behind it before the first gradient is written"""
-        self._zero_event = None
-        side = None
-        if beside and self.flat.is_cuda:
-            from . import _ops
-            side = _ops.side_stream(self.flat.device)
-        if side is not None and side != torch.cuda.current_stream(self.flat.device):
-            from . import _ops
-            _ops.fork(side, torch.cuda.current_stream(self.flat.device))
-            with torch.cuda.stream(side):
-                self.flat.zero_()
-                self._zero_event = torch.cuda.Event()
-                self._zero_event.record(side)
-        else:
-            self.flat.zero_()
+    def zero_grad(self):
+        self.flat.zero_()
         self._rebind()                   # keep the views even if someone set grads to None
-
-    def wait_zeroed(self):
-        ev = getattr(self, "_zero_event", None)
-        if ev is not None:
-            torch.cuda.current_stream(self.flat.device).wait_event(ev)
-            self._zero_event = None
 
     def finish(self):
         """Complete the gradient exchange of this step and average over ranks."""
@@ -301,12 +277,11 @@ class DataParallelStep:
 
     def _fwd_bwd(self, h_a, h_t, m_a, m_t, y, zero=True, scale=None):
         if zero:
-            self.buckets.zero_grad(beside=_ZERO_BESIDE)
+            self.buckets.zero_grad()
         logits, beta, _ = self.model(h_a, h_t, m_a, m_t)
         loss = self.loss_fn(logits, beta, y)
         if scale is not None:
             loss = loss * scale
-        self.buckets.wait_zeroed()
         if loss.is_cuda and scale is None:
             from . import _ops
             loss.backward(gradient=_ops.one(loss.device))      # the fused losses skip the multiply by this very tensor
@@ -460,6 +435,14 @@ class DataParallelStep:
                         self.buckets.finish()         # the warm-up steps exchange eagerly (every rank alike) and leave the buckets reset
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if collectives:
+                # The process group's watchdog thread polls the end event of every EAGER collective until it has seen it complete
+                # (every 100 ms).  The warm-up exchanges above are complete now, but not necessarily reaped -- and once the capture
+                # below pulls the group's communication stream into the capture, ROCm 7.2 answers a query of an event that was
+                # recorded on that stream with hipErrorCapturedEvent, which the watchdog turns into std::terminate (sporadic: 1 run
+                # in 8 aborted, gpurun_out/cap_8.log of round 4).  Two watchdog periods let it drain its list first.
+                import time
+                time.sleep(0.25)
             graph = torch.cuda.CUDAGraph()
             if seqs is not None and self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()       # the bucket graphs never run concurrently: one pool for all

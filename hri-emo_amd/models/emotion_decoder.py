@@ -17,14 +17,7 @@ def _memory16(memory):
     return m16
 
 
-import os as _os
-_HOIST_KV = _os.environ.get("HRIEMO_HOIST_KV", "1") != "0"
-# The first layer's query self-attention block (:42-43) reads the learned queries only, not the encoder: with HRIEMO_DECODER_PROLOGUE=1
-# FusionWithEmotionDecoder enqueues it on the side stream inside the first fusion layer, where that stream waits for the audio
-# branch, instead of on the decoder's chain behind the gate (EmotionDecoder._prologue); autograd replays its backward on that
-# stream.  Measured (round 3, same box, scripts_dev/replay_only.py 60): the gate -> loss span shrinks 406 -> 337 us and loss ->
-# gate backward 508 -> 458 us, the step 7.910 -> 7.894 ms: the launches cost elsewhere what they save in the tail.  Opt-in.
-_PROLOGUE = _os.environ.get("HRIEMO_DECODER_PROLOGUE", "0") == "1"
+_HOIST_KV = True           # the memory's K | V projections of all layers issued up front on the side stream (EmotionDecoder._fwd)
 
 
 class ExplainableDecoderLayer(nn.Module):
@@ -57,16 +50,12 @@ class ExplainableDecoderLayer(nn.Module):
                                               self.nhead, None, p, seed, self._site[0], self.batch_offset, False)     # :42-43
         return tgt, tgt32, seed
 
-    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need, kv_pre=None, kv_ready=None, self_done=None):
-        """self_done: the seed of this layer if tgt / tgt32 already ARE the self-attention sub-layer's output (EmotionDecoder._prologue)"""
+    def _fwd_pair(self, tgt, tgt32, memory, memory_key_padding_mask, need, kv_pre=None, kv_ready=None):
         B, L, _ = memory.shape
         kpm = _ops.mask_u8(memory_key_padding_mask, B, L)
         p = self.p if self.training else 0.0
         ca, s = self.cross_attn, self._site
-        if self_done is None:
-            tgt, tgt32, seed = self._self_block(tgt, tgt32)
-        else:
-            seed = self_done
+        tgt, tgt32, seed = self._self_block(tgt, tgt32)
         if kv_ready is not None:          # K | V of the memory were projected on the side stream (EmotionDecoder._fwd)
             torch.cuda.current_stream(memory.device).wait_event(kv_ready)
         tgt, tgt32, w = _ops.CrossAttnLN.apply(tgt, tgt32, memory, ca.in_proj_weight, ca.in_proj_bias,
@@ -109,31 +98,9 @@ class EmotionDecoder(nn.Module):
         out32 = self.emotion_queries.detach().float().unsqueeze(0).expand(B, -1, -1).contiguous() if _ops.TWIN else None
         return out, out32
 
-    def _prologue_applies(self, device):
-        return bool(_PROLOGUE and len(self.layers) > 0 and device.type == "cuda" and _ops.precision() == "bf16"
-                    and _ops.gemm_mode() == "bf16" and _ops.side_stream(device) is not None)
-
-    def _prologue(self, B, device):
-        """Everything of the decoder that does not depend on the encoder -- the broadcast queries and the first layer's query
-        self-attention block.  Called with the SIDE stream current (CrossModalBlock's side_hook: behind the text branch's first
-        self-attention stage, where that stream waits for the audio branch anyway; at the very top of the step the same launches
-        delayed the encoder by as much as they saved behind the gate); -> (tgt, tgt32, seed of layer 0, event) for _fwd(pre=...)."""
-        out, out32 = self._queries(B)
-        tgt, tgt32, seed = self.layers[0]._self_block(out, out32)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-        return tgt, tgt32, seed, ev
-
-    def _fwd(self, memory16, memory_key_padding_mask, need, out_dtype, pre=None):
+    def _fwd(self, memory16, memory_key_padding_mask, need, out_dtype):
         B = memory16.size(0)
-        if pre is None:
-            out, out32 = self._queries(B)
-        else:
-            out, out32 = pre[0], pre[1]
-            main = torch.cuda.current_stream(memory16.device)
-            main.wait_event(pre[3])
-            _ops.share(out, main)
-            _ops.share(out32, main)
+        out, out32 = self._queries(B)
         all_layers_attn = []
         if _ops.want_mx_copy(memory16.shape[0] * memory16.shape[1], memory16.shape[2]):
             # fp8 GEMM mode: every layer projects the same memory to K | V -- quantise it once
@@ -160,7 +127,7 @@ class EmotionDecoder(nn.Module):
                 _ops.share(kv, main)
         for i, layer in enumerate(self.layers):
             out, out32, attn_map = layer._fwd_pair(out, out32, memory16, memory_key_padding_mask, need, kvs[i],
-                                                   ready if i == 0 else None, pre[2] if (pre is not None and i == 0) else None)
+                                                   ready if i == 0 else None)
             if need and attn_map is not None:
                 all_layers_attn.append(attn_map)
         logits = None

@@ -11,22 +11,6 @@ from .beta_gate_tacfn import BetaGate
 from .emotion_decoder import EmotionDecoder
 
 
-import os as _os
-_PREFETCH = _os.environ.get("HRIEMO_PREFETCH_SHADOWS", "1") != "0"
-# all weight shadows of a step from two batched cast launches (hriemo_cast_f32_to_bf16_batch) instead of one ~5 us launch per
-# matrix.  Built in round 3 because the step's first GEMM starts 220 us into the replay behind a chain of 16 small casts
-# (profiles/r03_step_timeline.txt) -- and measured SLOWER on one box (8.19-8.23 vs 8.14 ms per step, scripts_dev/replay_only.py):
-# the graph runtime starts the audio branch late either way, and two bandwidth-heavy bursts at the top cost more than the small
-# casts that hide in gaps later.  Opt-in.
-_BATCHED_CASTS = _os.environ.get("HRIEMO_BATCHED_CASTS", "0") == "1"
-# where the gate / decoder casts are enqueued: in front of the step (0) or behind the first fusion layer (1).  In front, the
-# graph runtime runs those 14 side-stream launches and the text branch's first kernels before it starts the audio branch, whose
-# first GEMM begins ~300 us into the replay; behind the first layer the audio GEMM starts at 85 us -- and the text branch then
-# starts at 310 us instead: the encoder forward ends 20 us earlier and the step is unchanged (7.90 / 7.93 vs 7.91 / 7.92 ms,
-# same box).  The top of the step is not idle time, it is the text branch running first.  Opt-in.
-_PREFETCH_LATE = _os.environ.get("HRIEMO_PREFETCH_LATE", "0") == "1"
-
-
 class FusionWithEmotionDecoder(nn.Module):
     def __init__(self, d_model: int = 768, num_emotions: int = 4, n_heads: int = 8, num_layers_fusion: int = 2,
                  num_layers_decoder: int = 2, beta_hidden: int = 256, dropout: float = 0.1):
@@ -44,57 +28,26 @@ class FusionWithEmotionDecoder(nn.Module):
             if hasattr(m, "batch_offset"):
                 m.batch_offset = int(offset)
 
-    def _prefetch_shadows(self, device, late=False):
-        """bf16 copies of EVERY weight matrix of the step from two batched cast launches at the top of the step: the first
-        fusion layer's on the caller's stream (its GEMMs come first), everything else -- further layers, gate, decoder -- on the
-        side stream beside them.  Before: one ~5 us cast launch per matrix, 16 of them a serial chain on the side stream that
-        the step's first GEMM ended up behind (profiles/r03_step_timeline.txt: 220 us into the step), and the decoder's on its
-        latency-bound chain.  Returns the event the consumer stream waits for, or None (one stream / fp32 / fp8 mode)."""
-        if _ops.precision() != "bf16" or not device.type == "cuda" or not _PREFETCH:
+    def _prefetch_shadows(self, device):
+        """bf16 copies of the gate's and the decoder's weight matrices, cast on the side stream at the top of the step, beside the
+        first fusion layer, instead of one ~5 us launch in front of every GEMM of the decoder's latency-bound chain.  Returns the
+        event the consumer stream waits for, or None (one stream / fp32 / fp8 mode)."""
+        if _ops.precision() != "bf16" or not device.type == "cuda":
             return None
-        layers = list(self.cross_modal.layers)
-        batched = _ops.gemm_mode() == "bf16" and _BATCHED_CASTS
-        if batched and layers:
-            jobs = []
-            layers[0]._plan_shadows(jobs)
-            _ops.cast_batch(jobs)
         side = _ops.side_stream(device)
         if side is None:
-            if batched:
-                jobs = []
-                for blk in layers[1:]:
-                    blk._plan_shadows(jobs)
-                self._plan_tail_shadows(jobs)
-                _ops.cast_batch(jobs)
             return None
         main = torch.cuda.current_stream(device)
-        if not late:                                # late: the side stream is already behind the caller's stream (the first layer's fork)
-            _ops.fork(side, main)                   # the masters may have just been updated on the caller's stream
+        _ops.fork(side, main)                       # the masters may have just been updated on the caller's stream
         with torch.cuda.stream(side):
-            if batched:
-                jobs = []
-                for blk in layers[1:]:
-                    blk._plan_shadows(jobs)
-                self._plan_tail_shadows(jobs)
-                _ops.cast_batch(jobs)
-            else:
-                g = self.beta_gate
-                g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))
-                for layer in self.emotion_decoder.layers:
-                    layer._sh.prefetch((layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
-                                        layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight))
+            g = self.beta_gate
+            g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))
+            for layer in self.emotion_decoder.layers:
+                layer._sh.prefetch((layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
+                                    layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight))
             ev = torch.cuda.Event()
             ev.record(side)
         return ev
-
-    def _plan_tail_shadows(self, jobs):
-        g = self.beta_gate
-        g._sh.plan(g.mlp[0].weight, jobs)
-        g._sh.plan(g.mlp[2].weight, jobs)
-        for layer in self.emotion_decoder.layers:
-            for w in (layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
-                      layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight):
-                layer._sh.plan(w, jobs)
 
     def _ensure_3d(self, x):
         if x.dim() == 2:
@@ -133,31 +86,17 @@ class FusionWithEmotionDecoder(nn.Module):
         # the decoder's memory mask needs the two padding masks only (L_fused = T_t, beta_gate_tacfn.py:98-116): built here, not on
         # the decoder's serial chain behind the gate
         fused_early = self._build_fused_mask(mask_a, mask_t, h_t.size(1))
-        pre = [None]
-        dec, nb = self.emotion_decoder, a.shape[0]
-
-        def decoder_prologue():             # runs on the side stream, inside the first fusion layer (cross_modal_block_tacfn side_hook)
-            pre[0] = dec._prologue(nb, dev)
-
-        hook = decoder_prologue if dec._prologue_applies(a.device) else None
-        late = _PREFETCH_LATE and not _BATCHED_CASTS and len(self.cross_modal.layers) > 0
-        ready = [None if late else self._prefetch_shadows(a.device)]
-        dev = a.device
-
-        def prefetch_late():
-            ready[0] = self._prefetch_shadows(dev, late=True)
-
+        ready = self._prefetch_shadows(a.device)
         _ops.JOIN_SCOPE += 1          # logits, beta and z all depend on both branches: the encoder's gradient joins are safe
         try:
-            a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need,
-                                                                       prefetch_late if late else None, hook)
+            a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
         finally:
             _ops.JOIN_SCOPE -= 1
-        if ready[0] is not None:
-            torch.cuda.current_stream(a.device).wait_event(ready[0])
+        if ready is not None:
+            torch.cuda.current_stream(a.device).wait_event(ready)
         h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)
         fused_mask = fused_early if h_fusion.size(1) == h_t.size(1) else self._build_fused_mask(mask_a, mask_t, h_fusion.size(1))
-        z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype, pre[0])
+        z, logits, decoder_attns = self.emotion_decoder._fwd(h_fusion, fused_mask, need, out_dtype)
         if return_attention:
             return logits, beta, z, {"encoder": encoder_attns, "decoder": decoder_attns}
         return logits, beta, z

@@ -274,8 +274,8 @@ int hriemo_adamw_flat(float* p, const float* g, float* m, float* v, long n, floa
  * nseg | accumulate << 8 | first_block << 32, out0, out1, out2} with first_block the running sum of
  * nseg * ceil(w/32) over the preceding jobs and nblocks the total.  Deterministic (fixed summation order). */
 int hriemo_add_ln_bwd_partial_rows(int M, int d);
-/* Tuning / test hook: 0 (default) = LayerNorm(x + dropout(g)) forward and backward run the quad-mapped, software-pipelined kernels
- * where they are built (d = 256, 512, 768 or 1024, fp32 twin in and out, no MX copy); 1 = the chunk-mapped kernels everywhere.  Both mappings
+/* Tuning / test hook: 1 (default) = LayerNorm(x + dropout(g)) forward and backward run the chunk-mapped kernels; 0 = the quad-mapped,
+ * software-pipelined kernels where they are built (d = 256, 512, 768 or 1024, fp32 twin in and out, no MX copy).  Both mappings
  * draw the same dropout masks and differ by the summation order of the row statistics only.  Set it before any workspace is sized
  * (hriemo_add_ln_bwd_workspace_bytes / _partial_rows follow the variant). */
 int hriemo_rowops_force_variant(int variant);
@@ -332,7 +332,7 @@ int hriemo_fuse_f32(const float* w, const float* A, int La, const float* T, int 
  *    summation order; workspace >= hriemo_colsum_f32_workspace_bytes.
  *  - hriemo_add_ln_bwd_f32: backward of Y = LayerNorm(G + X) * gamma + beta (X may be NULL): dS = d loss / d (G + X) [M,d]
  *    (= dG = dX), dgamma / dbeta / dbias(= column sums of dS; may be NULL) overwritten or added to (accumulate); the row statistics
- *    are recomputed from G + X.  workspace >= hriemo_add_ln_bwd_f32_workspace_bytes(M, d).
+ *    are recomputed from G + X.  d <= 1024.  workspace >= hriemo_add_ln_bwd_f32_workspace_bytes(M, d).
  *  - hriemo_attn_bwd_f32: dQ, dK, dV of O = softmax(Q K^T / sqrt(hd) + key padding) V from Q, K, V, O, dO and the forward's lse, on
  *    v_mfma_f32_16x16x4_f32; two kernels (dQ per 64 queries, dK / dV per 64 keys), no atomics, fixed order; delta: scratch
  *    [B, H, Lq] floats (rowsum(dO * O), written by the first kernel for the second).  nn.MultiheadAttention, cross_modal_block_

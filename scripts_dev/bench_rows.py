@@ -39,7 +39,7 @@ for M, name in shapes:
             P = _ops._p
             res[v][1].append(timed(lambda: _lib.call("hriemo_add_ln_bwd_rows", P(dy), P(g), None, P(x32), P(gamma), P(mean), P(rstd), P(dx), P(dg),
                                                      None, None, None, 0, M, d, 0.1, 1, P(_ops.seed_word(g.device)), 2, 0, P(part), None, _ops._stream())))
-    _lib.call("hriemo_rowops_force_variant", 0)
+    _lib.call("hriemo_rowops_force_variant", 1)
     bf, bb = M * d * 12, M * d * 12
     for v, nm in ((1, "chunk"), (0, "quad ")):
         f, b = sorted(res[v][0]), sorted(res[v][1])

@@ -31,4 +31,4 @@ for name, d, ne in (("cfg1_train_p0", 128, 4), ("hd96_train_p0", 768, 6)):
         k = len(gr)
         print(f"{name}/{init}: err vs oracle median chunk {e1[k//2]:.4f} quad {e0[k//2]:.4f}; p90 chunk {e1[k*9//10]:.4f} quad {e0[k*9//10]:.4f}; "
               f"quad-vs-chunk median {dd[k//2]:.4f} max {dd[-1]:.4f}; z diff {rel(res[0][1], res[1][1]):.2e}; dh_a diff {rel(res[0][2], res[1][2]):.4f}", flush=True)
-_lib.call("hriemo_rowops_force_variant", 0)
+_lib.call("hriemo_rowops_force_variant", 1)

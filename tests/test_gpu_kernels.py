@@ -426,7 +426,7 @@ def test_add_ln_quad_mapped_kernels_equal_the_chunk_mapped_ones(ops, M, d, p):
             torch.cuda.synchronize()
             res[variant] = [t.float().cpu() for t in (y, y32, mean, rstd, dx, dg, dgam, dbet, dbias)]
     finally:
-        _lib.call("hriemo_rowops_force_variant", 0)
+        _lib.call("hriemo_rowops_force_variant", 1)
     keep = torch.from_numpy(hashrng.rows_mask(seed, site, M, d, p, roff)).float() if p > 0 else torch.ones(M, d)
     Gf = G.float().cpu().requires_grad_(True)
     Xf = X32.cpu().clone().requires_grad_(True)
