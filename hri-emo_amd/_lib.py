@@ -14,6 +14,7 @@ _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 _SIGS = {
     "hriemo_gemm_bf16": ("iiiiiplplplipipliplp", "i"),
     "hriemo_gemm_force_config": ("i", "i"),
+    "hriemo_gemm_debug_flags": ("i", "i"),
     "hriemo_gemm_colsum_rows": ("iiiii", "i"),
     "hriemo_gemm_bf16_group_tn": ("piip", "i"),
     "hriemo_gemm_bf16_split": ("iiiiiplplplpliiplp", "i"),
@@ -21,8 +22,10 @@ _SIGS = {
     "hriemo_mx8_scale_ld": ("i", "l"),
     "hriemo_quant_mx8": ("pliiiplplp", "i"),
     "hriemo_gemm_mx8": ("iiiplplplplplipiplp", "i"),
+    "hriemo_gemm_mx8_q": ("iiiplplplplplpiplplp", "i"),
     "hriemo_gemm_mx8_force_config": ("i", "i"),
     "hriemo_attn_fwd": ("plplplplppiiiiifQpIipp", "i"),
+    "hriemo_attn_fwd_q": ("plplplplppiiiiifQpIipplplp", "i"),
     "hriemo_attn_bwd": ("plplplplplplplplpppiiiiifQpIipppp", "i"),
     "hriemo_attn_fwd_varlen": ("plplplplpppiiiiifQpIipp", "i"),
     "hriemo_attn_bwd_varlen": ("plplplplplplplplppppiiiiifQpIipppp", "i"),

@@ -306,6 +306,39 @@ class Shadows:
         self._d[kb] = (vb, sb, STEP_ID)
         return sw, sb
 
+    def get_cat_mx8(self, parts):
+        """MX-fp8 form (bytes [rows, K], scales [K/32, ld]) of the row-wise concatenation of master slices, refreshed like
+        mx8_shadow: every slice is quantised from its fp32 master straight into its rows of ONE buffer (the scale matrix is
+        k-block major with one column per row, so a slice owns a column range of it)"""
+        key = ("catmx",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
+        ent = self._d.get(key)
+        ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
+        if CAPTURING or ent is None or ent[0] != ver:
+            rows = sum(r1 - r0 for _, r0, r1 in parts)
+            K = parts[0][0].shape[1]
+            dev = parts[0][0].device
+            L_ = _lib.lib()
+            ld = L_.hriemo_mx8_scale_ld(rows)
+            if ent is not None and ent[1][0].shape == (rows, K) and ent[1][0].device == dev:
+                q, sc = ent[1]
+            else:
+                q = torch.empty((rows, K), dtype=torch.uint8, device=dev)
+                sc = torch.zeros((K // 32, ld), dtype=torch.uint8, device=dev)
+            at = 0
+            for p, r0, r1 in parts:
+                _require_gpu(p)
+                _require_fp32_master(p)
+                src = p.detach()
+                if not src.is_contiguous():
+                    src = src.contiguous()
+                src = src[r0:r1]
+                _lib.call("hriemo_quant_mx8", _p(src), src.stride(0), 1, r1 - r0, K, q.data_ptr() + at * K, K, sc.data_ptr() + at, ld,
+                          _stream())
+                at += r1 - r0
+            ent = (ver, (q, sc))
+            self._d[key] = ent
+        return ent[1]
+
     def get_cat_vec(self, parts):
         """fp32 concatenation of bias slices ((param, r0, r1), ...), cached like the weight shadows"""
         key = ("catv",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
@@ -552,11 +585,19 @@ def quant_mx8(x):
     return q, sc
 
 
-def linear_fwd_mx8(xq, xs, wq, ws, bias, relu=False, out_f32=False):
-    """(xq, xs) [M,K] and (wq, ws) [N,K] quantised operands -> y [M,N] = x . w^T + bias"""
+def linear_fwd_mx8(xq, xs, wq, ws, bias, relu=False, out_f32=False, want_q=False):
+    """(xq, xs) [M,K] and (wq, ws) [N,K] quantised operands -> y [M,N] = x . w^T + bias; want_q: the epilogue also leaves the
+    MX-fp8 form of y (the next GEMM's operand) attached to y (tag_mx): no quantisation pass over [M, N]"""
     M, K = xq.shape
     N = wq.shape[0]
     y = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=xq.device)
+    if want_q and not out_f32 and N % 128 == 0:
+        ld = _lib.lib().hriemo_mx8_scale_ld(M)
+        q = torch.empty((M, N), dtype=torch.uint8, device=xq.device)
+        sc = torch.empty((N // 32, ld), dtype=torch.uint8, device=xq.device)
+        _lib.call("hriemo_gemm_mx8_q", M, N, K, _p(xq), xq.stride(0), _p(xs), xs.stride(0), _p(wq), wq.stride(0), _p(ws), ws.stride(0),
+                  _p(y), N, _p(bias), 1 if relu else 0, _p(q), N, _p(sc), ld, _stream())
+        return tag_mx(y, (q, sc))
     _lib.call("hriemo_gemm_mx8", M, N, K, _p(xq), xq.stride(0), _p(xs), xs.stride(0), _p(wq), wq.stride(0), _p(ws), ws.stride(0),
               _p(y), N, int(out_f32), _p(bias), 1 if relu else 0, None, 0, _stream())
     return y
@@ -605,8 +646,9 @@ def tag_mx(t, mx):
     return t
 
 
-def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False):
-    """y = x . W[rows]^T + bias[rows] on the configured operand format.  xop: Operand or bf16 tensor"""
+def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False, want_q=False):
+    """y = x . W[rows]^T + bias[rows] on the configured operand format.  xop: Operand or bf16 tensor; want_q (fp8 mode): y is the
+    operand of another GEMM -- its MX-fp8 form comes out of this GEMM's epilogue, attached to y"""
     x = xop.x if isinstance(xop, Operand) else xop
     K = x.shape[1]
     N = (rows[1] - rows[0]) if rows is not None else w.shape[0]
@@ -614,7 +656,7 @@ def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False):
     if gemm_mode() == "mx_fp8" and mx8_ok(K, N, x.shape[0]):
         xq, xs = xop.q() if isinstance(xop, Operand) else quant_mx8(x)
         wq, ws = mx8_shadow(sh, w, rows)
-        return linear_fwd_mx8(xq, xs, wq, ws, b, relu=relu, out_f32=out_f32)
+        return linear_fwd_mx8(xq, xs, wq, ws, b, relu=relu, out_f32=out_f32, want_q=want_q)
     wv = w16 if rows is None else w16[rows[0]:rows[1]]
     return linear_fwd(x, wv, b, relu=relu, out_f32=out_f32)
 
@@ -660,6 +702,16 @@ def attn_fwd(q, k, v, B, H, Lq, Lk, hd, kpm, p, seed, site, b_off, want_bits=Fal
     mb = None
     if want_bits and p > 0:
         mb = torch.empty(_lib.lib().hriemo_attn_mask_bytes(B, H, Lq, Lk) // 8, dtype=torch.int64, device=q.device)
+    if cu is None and hd % 32 == 0 and want_mx_copy(q.shape[0], H * hd):
+        # fp8 GEMM mode: the out-projection's operand leaves the attention kernel already quantised (tagged onto o)
+        ld = _lib.lib().hriemo_mx8_scale_ld(q.shape[0])
+        oq = torch.empty((q.shape[0], H * hd), dtype=torch.uint8, device=q.device)
+        so = torch.empty((H * hd // 32, ld), dtype=torch.uint8, device=q.device)
+        _lib.call("hriemo_attn_fwd_q", _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                  _p(kpm), _p(lse), B, H, Lq, Lk, hd, float(p), seed, _p(seed_word(q.device)), site, b_off, _p(mb), _p(oq), H * hd,
+                  _p(so), ld, _stream())
+        tag_mx(o, (oq, so))
+        return (o, lse, mb) if want_bits else (o, lse)
     if cu is not None:
         if kpm is not None:
             raise ValueError("attn_fwd: packed sequences carry their lengths; no key_padding_mask")
@@ -1166,7 +1218,7 @@ class SelfAttnLN(_GradModeAware, torch.autograd.Function):
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse, mbits = attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, AL, hd, AL) else \
             attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
-        g = proj_fwd(o, sh, w_out, w_out16, b_out)
+        g = proj_fwd(Operand(o, mx_of(o)), sh, w_out, w_out16, b_out)
         y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
                                              want_mx=want_mx_copy(M, d), rows=rows)
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
@@ -1253,7 +1305,7 @@ class CrossAttnLN(_GradModeAware, torch.autograd.Function):
         k, v = kv[:, :d], kv[:, d:]
         o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd, ALq) else \
             attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
-        g = proj_fwd(o, sh, w_out, w_out16, b_out)
+        g = proj_fwd(Operand(o, mx_of(o)), sh, w_out, w_out16, b_out)
         y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
                                              want_mx=want_mx_copy(B * Lq, d), rows=rows)
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
@@ -1496,7 +1548,14 @@ class SharedProjFn(torch.autograd.Function):
         B, L, d = x.shape
         x2 = _contig_bf16(x).view(B * L, d)
         wcat, bcat = sh.get_cat_wb(((wq, 0, d), (wkv, d, 3 * d)), ((bq, 0, d), (bkv, d, 3 * d)))
-        out = linear_fwd(x2, wcat, bcat)
+        if gemm_mode() == "mx_fp8" and mx8_ok(d, 3 * d, B * L):
+            # cfg 5: the same ONE N = 3d launch on MX-fp8 operands (the LayerNorm that produced x left its fp8 copy; the
+            # concatenated weight is quantised slice by slice into one buffer); the backward below is the bf16 one either way
+            xq, xs = Operand(x2, mx_of(x)).q()
+            wq8, ws8 = sh.get_cat_mx8(((wq, 0, d), (wkv, d, 3 * d)))
+            out = linear_fwd_mx8(xq, xs, wq8, ws8, bcat)
+        else:
+            out = linear_fwd(x2, wcat, bcat)
         ctx.save_for_backward(x2, wcat)
         ctx.cfg = (B, L, d)
         ctx.join, ctx.shared = join, shared
@@ -1603,7 +1662,7 @@ class FFNLN(_GradModeAware, torch.autograd.Function):
         x32 = _c32(x32)
         x32v = x32.view(M, d) if x32 is not None else None
         w1_16, w2_16 = sh.get(w1), sh.get(w2)
-        h = proj_fwd(Operand(x2, mx_of(x)), sh, w1, w1_16, b1, relu=True)
+        h = proj_fwd(Operand(x2, mx_of(x)), sh, w1, w1_16, b1, relu=True, want_q=p_mid == 0)
         hd_ = h
         if p_mid > 0:
             hd_ = torch.empty_like(h)
@@ -1611,7 +1670,7 @@ class FFNLN(_GradModeAware, torch.autograd.Function):
                 DROP_LOG.append(("rows", seed, site + 2, M, h.shape[1], float(p_mid), b_off * L))
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
-        g = proj_fwd(hd_, sh, w2, w2_16, b2)
+        g = proj_fwd(Operand(hd_, mx_of(hd_)), sh, w2, w2_16, b2)
         RL, rows = (seq.L, seq.idx) if seq is not None else (L, None)
         if seq is not None and p_mid > 0:
             raise ValueError("FFNLN: packed rows with a mid-FFN dropout are not built (the encoder's FFNs have none)")

@@ -48,6 +48,9 @@ struct AttnArgs {
   // stride of the lse / delta / mask-word side buffers, which keep their padded [B,H,Lq] indexing).  Every length >= 1.
   const int* cu_q;
   const int* cu_k;
+  // optional MX-fp8 copy of O for the out-projection GEMM (cfg 5's fp8 mode): bytes [B*Lq][ldoq] + E8M0 scales [H*HD/32][ldso]
+  uint8_t* Oq; long ldoq;
+  uint8_t* So; long ldso;
 };
 
 // Packed sequences: the kernels below index sample b's rows as b * L + r.  localize() turns the launch arguments into the view of
@@ -365,6 +368,45 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnArgs a0) {
       *(bf16x4*)(op + dt * 16) = w;
     }
     if (g == 0 && a.lse != nullptr) a.lse[((long)b * a.H + h) * a.Lq + q] = (m[qs] + log2f(l[qs])) * LN2;
+  }
+  if constexpr (DT % 2 == 0) {
+    if (a.Oq != nullptr) {            // kernel-uniform (fp8 GEMM mode): the MX-fp8 form of the stored O for the out-projection
+      // a 32-column MX block of row q = sub-tiles dt = 2k, 2k+1 over the four lane groups g of lane column i: 8 values per lane,
+      // block maximum over lanes i, i+16, i+32, i+48; quantises the ROUNDED bf16 values (bit-identical to hriemo_quant_mx8 of O)
+#pragma unroll
+      for (int qs = 0; qs < QW; ++qs) {
+        const int q = qbase + qs * 16 + i;
+        const float inv = (a.thr16 != 0 ? a.inv_keep : 1.f) / l[qs];
+        const long row = (long)b * a.Lq + min(q, a.Lq - 1);
+#pragma unroll
+        for (int kb = 0; kb < DT / 2; ++kb) {
+          float f[8];
+          float amax = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            f[j] = (float)(bf16_t)(o[qs][2 * kb + (j >> 2)][j & 3] * inv);
+            amax = fmaxf(amax, fabsf(f[j]));
+          }
+          amax = fmaxf(amax, __shfl_xor(amax, 16));
+          amax = fmaxf(amax, __shfl_xor(amax, 32));
+          const unsigned ab = __float_as_uint(amax);
+          int e = (int)(ab >> 23) - 8 + ((ab & 0x7fffffu) > 0x600000u ? 1 : 0);
+          e = amax == 0.f ? 0 : (e < 1 ? 1 : (e > 253 ? 253 : e));
+          const float sc = amax == 0.f ? 0.f : __uint_as_float((unsigned)(254 - e) << 23);
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * sc, f[1] * sc, w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * sc, f[3] * sc, w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * sc, f[5] * sc, w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * sc, f[7] * sc, w1, true);
+          if (q < a.Lq) {
+            uint8_t* oq = a.Oq + row * a.ldoq + h * HD + kb * 32 + 4 * g;
+            *(int*)oq = w0;
+            *(int*)(oq + 16) = w1;
+            if (g == 0) a.So[(long)((h * HD) / 32 + kb) * a.ldso + row] = (uint8_t)e;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -1498,11 +1540,16 @@ static int check_packed(const AttnArgs& a) {
 static int attn_fwd_impl(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                          long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
                          int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
-                         unsigned site, int b_offset, void* drop_mask_bits, const int* cu_q, const int* cu_k, hipStream_t st) {
+                         unsigned site, int b_offset, void* drop_mask_bits, const int* cu_q, const int* cu_k, hipStream_t st,
+                         void* Oq = nullptr, long ldoq = 0, void* So = nullptr, long ldso = 0) {
   AttnArgs a = {};
   a.cu_q = cu_q; a.cu_k = cu_k;
   a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V;
   a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.O = (bf16_t*)O; a.ldo = ldo;
+  a.Oq = (uint8_t*)Oq; a.ldoq = ldoq; a.So = (uint8_t*)So; a.ldso = ldso;
+  HRIEMO_CHECK(Oq == nullptr || (cu_q == nullptr && head_dim % 32 == 0 && So != nullptr && ldoq % 4 == 0 && ((uintptr_t)Oq % 4) == 0 &&
+                                 ldso >= (long)B * Lq),
+               "attn_fwd: the MX-fp8 copy of O needs padded rows, head_dim %% 32 == 0 and a scale buffer of >= B*Lq columns");
   a.kpm = key_padding_mask; a.lse = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk;
   a.scale = 1.0f / sqrtf((float)head_dim);
   fill_drop(a, p_drop, seed, seed_dev, site, b_offset);
@@ -1542,6 +1589,17 @@ extern "C" int hriemo_attn_fwd(const void* Q, long ldq, const void* K, long ldk,
                                unsigned site, int b_offset, void* drop_mask_bits, hipStream_t st) {
   return attn_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, key_padding_mask, lse, B, H, Lq, Lk, head_dim, p_drop, seed, seed_dev, site,
                        b_offset, drop_mask_bits, nullptr, nullptr, st);
+}
+// hriemo_attn_fwd that also leaves the MX-fp8 form of O (bytes Oq[B*Lq][ldoq], E8M0 scales So[H*hd/32][ldso]) for the
+// out-projection GEMM of the fp8 mode: no separate quantisation pass over O
+extern "C" int hriemo_attn_fwd_q(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
+                                 long ldo, const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq,
+                                 int Lk, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                                 unsigned site, int b_offset, void* drop_mask_bits, void* Oq, long ldoq, void* So, long ldso,
+                                 hipStream_t st) {
+  HRIEMO_CHECK(Oq != nullptr, "attn_fwd_q: Oq required");
+  return attn_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, key_padding_mask, lse, B, H, Lq, Lk, head_dim, p_drop, seed, seed_dev, site,
+                       b_offset, drop_mask_bits, nullptr, nullptr, st, Oq, ldoq, So, ldso);
 }
 extern "C" int hriemo_attn_fwd_varlen(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O,
                                       long ldo, const int* cu_seqlens_q, const int* cu_seqlens_k, float* lse, int B, int H,

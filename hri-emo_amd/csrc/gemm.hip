@@ -154,6 +154,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
   int cur = 0, nxt = NS - 1;          // ring slots of the stage being computed / being filled
 
   bool parked = false;                  // wave 0 parked the next-next id in qslot[0] at the end of the last tile
+  bool relax_first = false;             // this wave's last epilogue stored a full bf16 sub-tile (see First below)
   for (;;) {
     __builtin_amdgcn_s_barrier();       // stage 0 of this tile (confirmed per wave before its last epilogue) is visible
     if (parked) nwg = __builtin_amdgcn_readfirstlane(qslot[0]);
@@ -191,12 +192,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
       if constexpr (decltype(steady)::value) stage(nxt, T, it + NS - 1);
       else prefetch(it);
     };
+    constexpr int NST = OUTF32 ? 0 : MT * 2;            // 16-byte line stores of one wave's bf16 sub-tile
     auto retire_s = [&](int it, auto steady) {
-      if constexpr (decltype(steady)::value) wait_vmcnt<(NS - 2) * LPT>();
-      else retire_next(it);
+      if constexpr (decltype(steady)::value) {
+        // (NS >= 3 only: with two ring slots the stage this wait needs is the one this very K-step issued, YOUNGER than the stores)
+        if (NS >= 3 && NST > 0 && relax_first && it == 0) wait_vmcnt<((NS - 2) * LPT + NST) < 63 ? ((NS - 2) * LPT + NST) : 63>();
+        else wait_vmcnt<(NS - 2) * LPT>();
+      } else retire_next(it);
     };
     typedef std::integral_constant<bool, true> Steady;
     typedef std::integral_constant<bool, false> Tail;
+    // First K-step (it == 0, steady body) of a tile that follows an epilogue of THIS wave (round 4).  CDNA counts stores in vmcnt like loads and
+    // retires them in order, so the standard wait of that K-step -- "at most the NS-2 youngest stage groups outstanding", i.e. the
+    // stage that is needed next has landed -- also waited for the acknowledgement of every store of the epilogue, which sits in
+    // the queue between that (older) stage and the group this K-step has just issued: the store drain was 40-60 % of the
+    // epilogue's cost (round 3's ablation: 44.1 / 41.9 / 38.7 us full / no stores / no epilogue on 25600x768x768).  The stage it
+    // waits for is OLDER than the stores, so the exact count is (NS-2) groups + the NST stores of a full bf16 tile; the stores
+    // then have a whole K-step to be acknowledged before the next wait needs them gone.  Only when this wave's sub-tile was
+    // stored unpredicated (full tile, no column-sum stores): a skipped store would make the count too permissive.
+
     if constexpr (K32) {
       // Staggered two-group schedule (256x256 tile, 32-deep stages).  A SIMD hosts wave w (group 0) and wave
       // w + 4 (group 1).  Every K-step is an S-phase (LDS-DMA issue for stream position it+3, the 12 fragment
@@ -411,6 +425,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
       }
     }
     if (!has_next) break;
+    if (!OUTF32) {
+      const int rows_valid = p.M - (T.m0 + wm * MT * 16), cols_valid = p.N - (T.n0 + wn * 64);
+      relax_first = (p.flags & 1) && rows_valid >= MT * 16 && cols_valid >= 64 && p.cs == nullptr;
+    }
     T = decode(nwg);
     wg = nwg;
     if (dyn) {
@@ -492,6 +510,12 @@ int hriemo_num_cus() {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
   }
   return n;
+}
+static int g_gemm_flags = 1;        // GemmArgs.flags of every launch (bit 0: count the epilogue's stores in the next tile's first wait)
+extern "C" int hriemo_gemm_debug_flags(int flags) {   // tuning hook (A/B in one process): returns the previous value
+  const int prev = g_gemm_flags;
+  g_gemm_flags = flags;
+  return prev;
 }
 static int g_force_cfg = -1;
 extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev/bench_gemm.py); -1 = heuristic
@@ -631,6 +655,7 @@ static int gemm_impl(int ta, int tb, int M, int N, int K, const void* A, long ld
   a.C = C; a.ldc = ldc; a.bias = bias; a.aux = (const bf16_t*)aux; a.ldaux = ldaux; a.epi = epilogue;
   a.tiles_m = (M + kCfg[cfg].bm - 1) / kCfg[cfg].bm; a.tiles_n = (N + kCfg[cfg].bn - 1) / kCfg[cfg].bn;
   a.ws = workspace; a.accumulate = accumulate; a.sched = nullptr;
+  a.flags = g_gemm_flags;
   a.cs = colsum_partials;
   HRIEMO_CHECK(colsum_partials == nullptr || (epilogue == 2 && !c_is_f32), "gemm: column sums are built for the masked epilogue (2) with bf16 output");
   int splitk = 1;

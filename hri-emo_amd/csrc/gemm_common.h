@@ -17,6 +17,7 @@ struct GemmArgs {
   float* ws;
   int accumulate;
   unsigned* sched;   // per-launch work queue: [0..7] per-XCD next-unit counters, [8] blocks finished; nullptr = static walk
+  int flags;         // bit 0: the first K-step after an epilogue counts that epilogue's stores in its retire wait (gemm.hip)
   // optional column sums of the stored tile (EPI 2 only: the ReLU-masked dX of an FFN, whose column sums are the first Linear's
   // bias gradient): one fp32 partial row per wave row-block, [ceil(M / (wave tile rows))][N]; nullptr = none
   float* cs;
@@ -310,6 +311,19 @@ __device__ __forceinline__ void store_tile(f32x4 (&acc)[MT][NTL], const GemmArgs
           // plain global store, uniform base + per-lane 32-bit offset.  (A raw-buffer store with the same
           // offsets loses lanes on this path, nondeterministically, on 8-wave blocks; measured, not understood.)
           if (full || ok) *(u32x4*)(cbase + (long)((mi * 16 + k * 8) * p.ldc * 2) + line_c) = v;
+          if (EPI <= 1 && p.CQ != nullptr) {       // kernel-uniform: MX-fp8 copy of the stored (rounded) values for the NEXT GEMM
+            // a 32-column MX block = the 16-byte lines of lanes cc, cc^1, cc^2, cc^3 of one row: mx8_block's two xor-shuffles
+            float f8[8];
+            bf8_to_f32(__builtin_bit_cast(bf16x8, v), f8);
+            int e;
+            const __attribute__((ext_vector_type(2))) int w8 = mx8_block(f8, e);       // every lane takes part
+            const long qrow = mb + mi * 16 + k * 8 + rr;
+            const int qcol = nb + cc * 8;
+            if (full || ok) {
+              *(__attribute__((ext_vector_type(2))) int*)(p.CQ + qrow * p.ldcq + qcol) = w8;
+              if ((cc & 3) == 0) p.SC[(long)(qcol >> 5) * p.ldsc + qrow] = (uint8_t)e;
+            }
+          }
         }
       }
     }

@@ -341,9 +341,9 @@ static void launch_mx(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_mx8_kernel<OUTF32, BM, BN, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, q);
 }
 
-extern "C" int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
-                               const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
-                               const void* aux, long ldaux, hipStream_t st) {
+static int gemm_mx8_impl(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
+                         const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
+                         const void* aux, long ldaux, void* CQ, long ldcq, void* SC, long ldsc, hipStream_t st) {
   HRIEMO_CHECK(M > 0 && N > 0 && K > 0, "gemm_mx8: empty problem M=%d N=%d K=%d", M, N, K);
   HRIEMO_CHECK(K % 128 == 0, "gemm_mx8: K=%d must be a multiple of 128 (one scaled MFMA step)", K);
   HRIEMO_CHECK(N % 8 == 0, "gemm_mx8: N=%d must be a multiple of 8", N);
@@ -363,6 +363,11 @@ extern "C" int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, co
   a.C = C; a.ldc = ldc; a.bias = bias; a.aux = (const bf16_t*)aux; a.ldaux = ldaux; a.epi = epilogue;
   a.tiles_m = (M + kMx[cfg].bm - 1) / kMx[cfg].bm; a.tiles_n = (N + kMx[cfg].bn - 1) / kMx[cfg].bn;
   a.splitk = 1; a.k_per_split = K; a.ws = nullptr; a.accumulate = 0; a.sched = nullptr;
+  if (CQ != nullptr) {
+    HRIEMO_CHECK(!c_is_f32 && epilogue <= 1 && N % 32 == 0 && SC != nullptr && ldcq % 8 == 0 && ((uintptr_t)CQ % 8) == 0 && ldsc >= M,
+                 "gemm_mx8: the fused MX copy of the output needs a bf16 output, epilogue 0 / 1, N %% 32 == 0 and a scale buffer");
+    a.CQ = (uint8_t*)CQ; a.ldcq = ldcq; a.SC = (uint8_t*)SC; a.ldsc = ldsc;
+  }
   hriemo_prof_begin(HP_GEMM_MX8, st);
   if (c_is_f32) {
     if (cfg == 0) launch_mx<1, 256, 128, 4, 2>(a, st); else launch_mx<1, 128, 128, 2, 2>(a, st);
@@ -372,6 +377,20 @@ extern "C" int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, co
   HRIEMO_LAUNCH_CHECK("gemm_mx8_kernel");
   hriemo_prof_end(HP_GEMM_MX8, st, 2.0 * M * N * K);
   return 0;
+}
+
+extern "C" int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
+                               const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
+                               const void* aux, long ldaux, hipStream_t st) {
+  return gemm_mx8_impl(M, N, K, Aq, lda, SA, ldsa, Bq, ldb, SB, ldsb, C, ldc, c_is_f32, bias, epilogue, aux, ldaux, nullptr, 0, nullptr, 0, st);
+}
+// same, and the epilogue also leaves the MX-fp8 form of the bf16 output it stores -- bytes CQ[M][ldcq], scales SC[N/32][ldsc] -- for
+// the GEMM that reads this output next (FFN1's ReLU output as FFN2's operand): no separate quantisation pass over [M, N]
+extern "C" int hriemo_gemm_mx8_q(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
+                                 const void* SB, long ldsb, void* C, long ldc, const float* bias, int epilogue, void* CQ, long ldcq,
+                                 void* SC, long ldsc, hipStream_t st) {
+  HRIEMO_CHECK(CQ != nullptr, "gemm_mx8_q: CQ required");
+  return gemm_mx8_impl(M, N, K, Aq, lda, SA, ldsa, Bq, ldb, SB, ldsb, C, ldc, 0, bias, epilogue, nullptr, 0, CQ, ldcq, SC, ldsc, st);
 }
 
 extern "C" long hriemo_mx8_scale_ld(int rows) { return ((long)rows + 255) / 256 * 256; }

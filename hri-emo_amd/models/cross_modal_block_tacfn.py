@@ -98,7 +98,7 @@ class CrossModalBlock(nn.Module):
         use_kv = not fp32
         join_for = lambda x: _ops.grad_join(2) if (use_kv and x.requires_grad) else None          # noqa: E731
         d = a.shape[2]
-        shared = use_kv and _ops.shared_proj() and _ops.gemm_mode() == "bf16"
+        shared = use_kv and _ops.shared_proj()
         if shared and side is None:
             a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)   # :74-81
             t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)   # :85-92

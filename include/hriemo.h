@@ -66,6 +66,10 @@ int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, 
                             const void* aux, long ldaux, float* colsum_partials, hriemo_stream_t stream);
 /* tuning hook: force one of the built tile configurations (-1 = built-in heuristic) */
 int hriemo_gemm_force_config(int cfg);
+/* Tuning hook (A/B measurements in one process): GemmArgs.flags of every following launch; returns the previous value.  Bit 0
+ * (default on): in the 3-stage 256x128 kernel the first K-step after an epilogue counts that epilogue's stores in its retire wait
+ * instead of waiting for their acknowledgement (csrc/gemm.hip, `First`). */
+int hriemo_gemm_debug_flags(int flags);
 
 /* ---- MX-fp8 operand path (BASELINE.json configs[4], "fp8 MFMA path"): the same nn.Linear / in-projection / out-projection
  * sites as hriemo_gemm_bf16 in the FORWARD direction (models/cross_modal_block_tacfn.py:24-52, models/emotion_decoder.py:14-27),
@@ -82,6 +86,12 @@ int hriemo_quant_mx8(const void* X, long ldx, int src_is_f32, int M, int K, void
 int hriemo_gemm_mx8(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
                     const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
                     const void* aux, long ldaux, hriemo_stream_t stream);
+/* hriemo_gemm_mx8 with bf16 output (epilogue 0 / 1) whose epilogue ALSO writes the MX-fp8 form of the values it stores: bytes
+ * CQ[M][ldcq] + E8M0 scales SC[N/32][ldsc] (ldsc >= M, a multiple of 256), bit-identical to hriemo_quant_mx8 of C -- the operand
+ * of the next GEMM (FFN1 -> FFN2, models/cross_modal_block_tacfn.py:43-52) without a quantisation pass of its own.  N % 32 == 0. */
+int hriemo_gemm_mx8_q(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
+                      const void* SB, long ldsb, void* C, long ldc, const float* bias, int epilogue, void* CQ, long ldcq,
+                      void* SC, long ldsc, hriemo_stream_t stream);
 int hriemo_gemm_mx8_force_config(int cfg);
 
 /* ---- attention core: softmax(QK^T/sqrt(hd) + mask) -> dropout -> .V per (batch, head), flash style.
@@ -121,6 +131,12 @@ int hriemo_attn_bwd_kv_colsum_rows(int B, int H, int Lq, int Lk, int head_dim);
  * the functions above (so hriemo_attn_mask_bytes / *_colsum_rows are asked with the maxima).  Same arithmetic, same dropout
  * mask (it is keyed by position within the sequence), results on the valid rows identical to the padded call with a
  * key_padding_mask. */
+/* hriemo_attn_fwd whose epilogue also writes the MX-fp8 form of O -- bytes Oq[B*Lq][ldoq], E8M0 scales So[H*hd/32][ldso] (ldso >=
+ * B*Lq, a multiple of 256), bit-identical to hriemo_quant_mx8 of O -- for the out-projection GEMM of the fp8 mode.  head_dim % 32 == 0. */
+int hriemo_attn_fwd_q(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
+                      const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim, float p_drop,
+                      unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset, void* drop_mask_bits,
+                      void* Oq, long ldoq, void* So, long ldso, hriemo_stream_t stream);
 int hriemo_attn_fwd_varlen(const void* Q, long ldq, const void* K, long ldk, const void* V, long ldv, void* O, long ldo,
                            const int* cu_seqlens_q, const int* cu_seqlens_k, float* lse, int B, int H, int max_len_q,
                            int max_len_k, int head_dim, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,

@@ -7,6 +7,8 @@
  * GEMM on random data vs the emulated operands multiplied in fp64;
  * the module at cfg-5 dimensions against the fp32 oracle with the tolerance stated below and the oracle-with-
    emulated-fp8-operands as the yardstick (same method as the bf16 autocast yardstick)."""
+import math
+
 import pytest
 import torch
 
@@ -92,6 +94,60 @@ def test_gemm_mx8_exact_on_integer_operands(ops, M, N, K, cfg):
         assert torch.equal(yf.cpu(), ref)
     finally:
         L.hriemo_gemm_mx8_force_config(-1)
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1])
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 512, 256, True), (12800, 4096, 1024, True), (300, 128, 640, False), (8192, 1024, 1024, False)])
+def test_gemm_mx8_epilogue_leaves_the_quantised_output(ops, M, N, K, relu, cfg):
+    """hriemo_gemm_mx8_q (round 4): the epilogue that stores the bf16 tile also writes its MX-fp8 form -- bytes and E8M0 scales must
+    be bit-identical to hriemo_quant_mx8 of the stored output (what FFN2 used to read from a separate pass), on full and edge
+    tiles, with and without ReLU; the bf16 output itself must equal the plain launch's"""
+    from hri_emo_amd import _lib
+    L = _lib.lib()
+    L.hriemo_gemm_mx8_force_config(cfg)
+    try:
+        g = torch.Generator().manual_seed(M + N)
+        A = (torch.randn(M, K, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).bfloat16().cuda()
+        W = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+        b = torch.randn(N, generator=g).cuda()
+        aq, as_ = ops.quant_mx8(A)
+        wq, ws = ops.quant_mx8(W)
+        y0 = ops.linear_fwd_mx8(aq, as_, wq, ws, b, relu=relu)
+        y1 = ops.linear_fwd_mx8(aq, as_, wq, ws, b, relu=relu, want_q=True)
+        q1, s1 = ops.mx_of(y1)
+        assert torch.equal(y0, y1)
+        q2, s2 = ops.quant_mx8(y0)
+        assert torch.equal(q1, q2), float((q1 != q2).float().mean())
+        assert torch.equal(s1[:, :M], s2[:, :M])
+    finally:
+        L.hriemo_gemm_mx8_force_config(-1)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,p", [(8, 8, 400, 128, 128, 0.1), (16, 8, 128, 400, 128, 0.0), (10, 8, 130, 70, 64, 0.1), (40, 4, 50, 33, 32, 0.1),
+                                            (16, 8, 100, 100, 96, 0.1)])
+def test_attention_forward_leaves_the_quantised_output(ops, monkeypatch, B, H, Lq, Lk, hd, p):
+    """hriemo_attn_fwd_q (round 4, fp8 GEMM mode): the attention forward's epilogue also writes the MX-fp8 form of O -- bit-identical
+    to hriemo_quant_mx8 of the O it stores (ragged keys, dropout, query tails, both tile widths); O and lse equal the plain launch's"""
+    d = H * hd
+    g = torch.Generator().manual_seed(B + Lq)
+    q = torch.randn(B * Lq, d, generator=g).bfloat16().cuda()
+    kv = torch.randn(B * Lk, 2 * d, generator=g).bfloat16().cuda()
+    lk = torch.randint(1, Lk + 1, (B,), generator=g)
+    kpm = (torch.arange(Lk)[None] >= lk[:, None]).cuda().view(torch.uint8)
+    o0, lse0 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Lq, Lk, hd, kpm, p, 77, 3, 0)
+    assert ops.mx_of(o0) is None
+    monkeypatch.setattr(ops, "GEMM_MODE", "mx_fp8")
+    if d % 128 == 0 and B * Lq >= ops.MX_MIN_ROWS:
+        o1, lse1 = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Lq, Lk, hd, kpm, p, 77, 3, 0)
+        assert torch.equal(o0, o1) and torch.equal(lse0, lse1)
+        oq, so = ops.mx_of(o1)
+        q2, s2 = ops.quant_mx8(o0)
+        M = B * Lq
+        assert torch.equal(oq, q2), float((oq != q2).float().mean())
+        assert torch.equal(so[:, :M], s2[:, :M])
+    else:
+        o1, _ = ops.attn_fwd(q, kv[:, :d], kv[:, d:], B, H, Lq, Lk, hd, kpm, p, 77, 3, 0)
+        assert ops.mx_of(o1) is None and torch.equal(o0, o1)
 
 
 def test_gemm_mx8_random_operands_vs_emulated_product(ops):
