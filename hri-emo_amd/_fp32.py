@@ -9,8 +9,10 @@ fp32 row kernels for LayerNorm, the gate and the head.  This file is the host-si
 function per sub-layer Function of _ops.py, which dispatches here and stays the autograd node.
 
 Activations travel as fp32 tensors: every sub-layer still returns the (bf16 copy, fp32) pair of the product path, consumers read
-the fp32 member, and gradients flow back through the fp32 slots.  Dropout is not built into the fp32 kernels: a sub-layer that
-would have to drop (training mode, p > 0) raises instead of silently dropping nothing -- the mode trains with dropout = 0.
+the fp32 member, and gradients flow back through the fp32 slots.  Dropout (the reference's trainer keeps the modules' default 0.1):
+the fp32 kernels drop where the bf16 ones do -- attention weights, sub-layer outputs before the residual add, the decoder FFN's
+hidden layer -- from the same counter hash with the same (seed, site, offset) keys, so a model draws the same masks in either
+precision; the backward replays them, nothing is stored.
 
 Reference arithmetic: models/cross_modal_block_tacfn.py:70-125, models/beta_gate_tacfn.py:68-118, models/emotion_decoder.py:30-64,
 116-162 (all fp32 nn.Modules)."""
@@ -27,10 +29,16 @@ def recording(ctx):
     return _ops.recording(ctx)
 
 
-def refuse_dropout(ctx, p, what):
-    if p > 0 and recording(ctx):
-        raise NotImplementedError(f"{what}: the fp32-tolerance mode trains with dropout = 0 (its kernels do not drop); "
-                                  f"got p = {p} in training mode -- build the model with dropout=0.0 or train on the bf16 path")
+def _drop_args(drop, dev):
+    """(p, seed, site, offset) | None -> the five dropout arguments of an fp32 kernel"""
+    if drop is None or drop[0] <= 0:
+        return 0.0, 0, None, 0, 0
+    p, seed, site, off = drop
+    return float(p), seed, _ops._p(_ops.seed_word(dev)), site, off
+
+
+def _on(drop):
+    return drop is not None and drop[0] > 0
 
 
 def tag32(t16, t32):
@@ -151,47 +159,68 @@ def colsum(x32, mask=None):
 
 
 # ----------------------------------------------------------------------------- attention cores, LayerNorm
-def attn(q, k, v, B, H, Lq, Lk, hd, kpm, want_lse=False):
+def attn(q, k, v, B, H, Lq, Lk, hd, kpm, want_lse=False, drop=None):
+    """drop = (p, seed, site, b_offset): dropout on the attention weights (the keys of _ops.attn_fwd)"""
     o = _new((B * Lq, H * hd), q)
     lse = _new((B, H, Lq), q) if want_lse else None
+    if _on(drop) and _ops.DROP_LOG is not None:
+        _ops.DROP_LOG.append(("attn", drop[1], drop[2], B, H, Lq, Lk, float(drop[0]), drop[3]))
     _lib.call("hriemo_attn_fwd_f32", _ops._p(q), q.stride(0), _ops._p(k), k.stride(0), _ops._p(v), v.stride(0), _ops._p(o), H * hd,
-              _ops._p(kpm), _ops._p(lse), B, H, Lq, Lk, hd, _ops._stream())
+              _ops._p(kpm), _ops._p(lse), B, H, Lq, Lk, hd, *_drop_args(drop, q.device), _ops._stream())
     return o, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, H, Lq, Lk, hd, kpm):
+def attn_bwd(q, k, v, o, do, lse, dq, dk, dv, B, H, Lq, Lk, hd, kpm, drop=None):
     delta = _new((B, H, Lq), q)
     _lib.call("hriemo_attn_bwd_f32", _ops._p(q), q.stride(0), _ops._p(k), k.stride(0), _ops._p(v), v.stride(0), _ops._p(o), o.stride(0),
               _ops._p(do), do.stride(0), _ops._p(kpm), _ops._p(lse), _ops._p(dq), dq.stride(0), _ops._p(dk), dk.stride(0), _ops._p(dv),
-              dv.stride(0), _ops._p(delta), B, H, Lq, Lk, hd, _ops._stream())
+              dv.stride(0), _ops._p(delta), B, H, Lq, Lk, hd, *_drop_args(drop, q.device), _ops._stream())
 
 
-def probs(q, k, B, H, Lq, Lk, hd, kpm, lse):
+def probs(q, k, B, H, Lq, Lk, hd, kpm, lse, drop=None):
     p = _new((B, Lq, Lk), q)
     _lib.call("hriemo_attn_probs_f32", _ops._p(q), q.stride(0), _ops._p(k), k.stride(0), _ops._p(kpm), _ops._p(lse), _ops._p(p), B, H,
-              Lq, Lk, hd, _ops._stream())
+              Lq, Lk, hd, *_drop_args(drop, q.device), _ops._stream())
     return p
 
 
-def add_ln(g32, x32, gamma, beta, want16=True):
-    """LayerNorm(x32 + g32) (x32 may be None) -> (bf16 copy | None, fp32)"""
+def add_ln(g32, x32, gamma, beta, want16=True, drop=None):
+    """LayerNorm(x32 + drop(g32)) (x32 may be None) -> (bf16 copy | None, fp32); drop = (p, seed, site, row_offset) as
+    _ops.add_ln_fwd"""
     M, d = g32.shape
     y32 = _new((M, d), g32)
     y16 = _new((M, d), g32, BF16) if want16 else None
+    if _on(drop) and _ops.DROP_LOG is not None:
+        _ops.DROP_LOG.append(("rows", drop[1], drop[2], M, d, float(drop[0]), drop[3]))
     _lib.call("hriemo_add_ln_f32", _ops._p(g32), _ops._p(x32), _ops._p(gamma.detach()), _ops._p(beta.detach()), _ops._p(y32),
-              _ops._p(y16), M, d, _ops._EPS, _ops._stream())
+              _ops._p(y16), M, d, _ops._EPS, *_drop_args(drop, g32.device), _ops._stream())
     return y16, y32
 
 
-def add_ln_bwd(dy32, g32, x32, gamma, want_dbias=True):
-    """backward of LayerNorm(x32 + g32): -> (dS [M,d] = gradient of the sum, dgamma, dbeta, dbias = colsum(dS) | None)"""
+def add_ln_bwd(dy32, g32, x32, gamma, want_dbias=True, drop=None):
+    """backward of LayerNorm(x32 + drop(g32)): -> (dS [M,d] = gradient of the sum = dX, dG = gradient of g32 (dS itself without
+    dropout), dgamma, dbeta, dbias = colsum(dG) | None)"""
     M, d = g32.shape
     ds = _new((M, d), g32)
+    dg = _new((M, d), g32) if _on(drop) else None
     stats = _new((3, d), g32)
     ws = _ws(_lib.lib().hriemo_add_ln_bwd_f32_workspace_bytes(M, d), g32.device)
-    _lib.call("hriemo_add_ln_bwd_f32", _ops._p(dy32), _ops._p(g32), _ops._p(x32), _ops._p(gamma.detach()), _ops._p(ds), _ops._p(stats[0]),
-              _ops._p(stats[1]), _ops._p(stats[2]) if want_dbias else None, 0, M, d, _ops._EPS, _ops._p(ws), _ops._stream())
-    return ds, stats[0], stats[1], (stats[2] if want_dbias else None)
+    _lib.call("hriemo_add_ln_bwd_f32", _ops._p(dy32), _ops._p(g32), _ops._p(x32), _ops._p(gamma.detach()), _ops._p(ds), _ops._p(dg),
+              _ops._p(stats[0]), _ops._p(stats[1]), _ops._p(stats[2]) if want_dbias else None, 0, M, d, _ops._EPS,
+              *_drop_args(drop, g32.device), _ops._p(ws), _ops._stream())
+    return ds, (dg if dg is not None else ds), stats[0], stats[1], (stats[2] if want_dbias else None)
+
+
+def dropout(x32, drop, relu=False, gate=None, log=True):
+    """drop(relu ? max(x, 0) : x) [* (gate > 0)]: the FFN's hidden dropout (forward: relu; backward: x = gradient, gate = the
+    pre-activations, log=False)"""
+    M, N = x32.shape
+    y = _new((M, N), x32)
+    if log and _on(drop) and _ops.DROP_LOG is not None:
+        _ops.DROP_LOG.append(("rows", drop[1], drop[2], M, N, float(drop[0]), drop[3]))
+    _lib.call("hriemo_dropout_f32", _ops._p(_c(x32)), _ops._p(y), M, N, int(relu), _ops._p(gate), *_drop_args(drop, x32.device),
+              _ops._stream())
+    return y
 
 
 def _twin(x, x32):
@@ -222,25 +251,33 @@ def _route(ctx, dx32, x_slot, x32_slot, shape):
 
 
 # ----------------------------------------------------------------------------- sub-layers (same results tuple as the Functions)
-def self_attn_ln(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p=0.0):
+def _drops(p, seed, site, b_off, rows_per_sample):
+    """the two dropout sites of an attention sub-layer, keyed as the bf16 Functions key them (_ops.SelfAttnLN.forward)"""
+    if p <= 0:
+        return None, None
+    return (p, seed, site, b_off), (p, seed, site + 1, b_off * rows_per_sample)
+
+
+def self_attn_ln(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p=0.0, seed=0, site=0, b_off=0):
     _ops._require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
     _ops._require_gpu(x)
-    refuse_dropout(ctx, p, "self-attention sub-layer")
     B, L, d = x.shape
     hd = _ops._heads(d, H)
     rec = recording(ctx)
+    d_attn, d_res = _drops(p, seed, site, b_off, L)
     xf = _twin(x, x32).view(B * L, d)
     qkv = linear(xf, sh, w_in, b_in)
     q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
-    o, lse = attn(q, k, v, B, H, L, L, hd, kpm, want_lse=need_w or rec)
+    o, lse = attn(q, k, v, B, H, L, L, hd, kpm, want_lse=need_w or rec, drop=d_attn)
     g = linear(o, sh, w_out, b_out)
-    y16, y32 = add_ln(g, xf, gamma, beta)
-    pr = probs(q, k, B, H, L, L, hd, kpm, lse) if need_w else None
+    y16, y32 = add_ln(g, xf, gamma, beta, drop=d_res)
+    pr = probs(q, k, B, H, L, L, hd, kpm, lse, drop=d_attn) if need_w else None
     ctx.fp32 = True
     if rec:
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(xf, qkv, o, lse, g, kpm)
         ctx.f32_cfg = (B, L, d, H, hd)
+        ctx.f32_drop = (d_attn, d_res)
         ctx.f32_params = (w_in, b_in, w_out, b_out, gamma, beta, sh)
         ctx.f32_from_twin, ctx.f32_x_dtype = x32 is not None, x.dtype
         if pr is not None:
@@ -253,12 +290,14 @@ def self_attn_ln_bwd(ctx, dy, dy32):
     B, L, d, H, hd = ctx.f32_cfg
     w_in, b_in, w_out, b_out, gamma, beta, sh = ctx.f32_params
     M = B * L
+    d_attn, d_res = ctx.f32_drop
     dyt = _total(dy, dy32, (M, d))
-    ds, dgamma, dbeta, db_out = add_ln_bwd(dyt, g, xf, gamma)
-    dw_out = linear_dw(ds, o)
-    do = linear_dx(ds, sh, w_out)
+    ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dyt, g, xf, gamma, drop=d_res)
+    dw_out = linear_dw(dg, o)
+    do = linear_dx(dg, sh, w_out)
     dqkv = _new((M, 3 * d), xf)
-    attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, L, L, hd, kpm)
+    attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], o, do, lse, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, H, L, L, hd, kpm,
+             drop=d_attn)
     dw_in = linear_dw(dqkv, xf)
     db_in = colsum(dqkv)
     dx = linear_dx(dqkv, sh, w_in, into=ds)            # + the residual path's gradient
@@ -266,28 +305,29 @@ def self_attn_ln_bwd(ctx, dy, dy32):
     return (gx[0], gx[1], dw_in, db_in, dw_out, db_out, dgamma, dbeta) + (None,) * 8
 
 
-def cross_attn_ln(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p=0.0):
+def cross_attn_ln(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p=0.0, seed=0, site=0, b_off=0):
     _ops._require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
     _ops._require_gpu(xq)
-    refuse_dropout(ctx, p, "cross-attention sub-layer")
     B, Lq, d = xq.shape
     Lk = xkv.shape[1]
     hd = _ops._heads(d, H)
     rec = recording(ctx)
+    d_attn, d_res = _drops(p, seed, site, b_off, Lq)
     xqf = _twin(xq, xq32).view(B * Lq, d)
     xkvf = _c(f32_of(xkv)).view(B * Lk, d)
     q = linear(xqf, sh, w_in, b_in, rows=(0, d))
     kv = linear(xkvf, sh, w_in, b_in, rows=(d, 3 * d))
     k, v = kv[:, :d], kv[:, d:]
-    o, lse = attn(q, k, v, B, H, Lq, Lk, hd, kpm, want_lse=need_w or rec)
+    o, lse = attn(q, k, v, B, H, Lq, Lk, hd, kpm, want_lse=need_w or rec, drop=d_attn)
     g = linear(o, sh, w_out, b_out)
-    y16, y32 = add_ln(g, xqf, gamma, beta)
-    pr = probs(q, k, B, H, Lq, Lk, hd, kpm, lse) if need_w else None
+    y16, y32 = add_ln(g, xqf, gamma, beta, drop=d_res)
+    pr = probs(q, k, B, H, Lq, Lk, hd, kpm, lse, drop=d_attn) if need_w else None
     ctx.fp32 = True
     if rec:
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(xqf, xkvf, q, kv, o, lse, g, kpm)
         ctx.f32_cfg = (B, Lq, Lk, d, H, hd)
+        ctx.f32_drop = (d_attn, d_res)
         ctx.f32_params = (w_in, b_in, w_out, b_out, gamma, beta, sh)
         ctx.f32_from_twin, ctx.f32_x_dtype, ctx.f32_kv_dtype = xq32 is not None, xq.dtype, xkv.dtype
         if pr is not None:
@@ -299,13 +339,14 @@ def cross_attn_ln_bwd(ctx, dy, dy32):
     xqf, xkvf, q, kv, o, lse, g, kpm = ctx.saved_tensors
     B, Lq, Lk, d, H, hd = ctx.f32_cfg
     w_in, b_in, w_out, b_out, gamma, beta, sh = ctx.f32_params
+    d_attn, d_res = ctx.f32_drop
     dyt = _total(dy, dy32, (B * Lq, d))
-    ds, dgamma, dbeta, db_out = add_ln_bwd(dyt, g, xqf, gamma)
-    dw_out = linear_dw(ds, o)
-    do = linear_dx(ds, sh, w_out)
+    ds, dg, dgamma, dbeta, db_out = add_ln_bwd(dyt, g, xqf, gamma, drop=d_res)
+    dw_out = linear_dw(dg, o)
+    do = linear_dx(dg, sh, w_out)
     dq = _new((B * Lq, d), xqf)
     dkv = _new((B * Lk, 2 * d), xqf)
-    attn_bwd(q, kv[:, :d], kv[:, d:], o, do, lse, dq, dkv[:, :d], dkv[:, d:], B, H, Lq, Lk, hd, kpm)
+    attn_bwd(q, kv[:, :d], kv[:, d:], o, do, lse, dq, dkv[:, :d], dkv[:, d:], B, H, Lq, Lk, hd, kpm, drop=d_attn)
     dw_in = _new((3 * d, d), xqf)
     dw_in[:d].copy_(linear_dw(dq, xqf))
     dw_in[d:].copy_(linear_dw(dkv, xkvf))
@@ -318,21 +359,27 @@ def cross_attn_ln_bwd(ctx, dy, dy32):
     return (gx[0], gx[1], dxkv, dw_in, db_in, dw_out, db_out, dgamma, dbeta) + (None,) * 12
 
 
-def ffn_ln(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p=0.0, p_mid=0.0):
+def ffn_ln(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p=0.0, p_mid=0.0, seed=0, site=0, b_off=0):
     _ops._require_fp32_masters(w1, b1, w2, b2, gamma, beta)
     _ops._require_gpu(x)
-    refuse_dropout(ctx, max(p, p_mid), "feed-forward sub-layer")
     shape = x.shape
     d = shape[-1]
+    L = shape[1] if len(shape) == 3 else 1
+    d_res = (p, seed, site + 1, b_off * L) if p > 0 else None
+    d_mid = (p_mid, seed, site + 2, b_off * L) if p_mid > 0 else None        # keys of _ops.FFNLN.forward
     xf = _twin(x, x32).view(-1, d)
     h = linear(xf, sh, w1, b1)
-    g = linear(h, sh, w2, b2, relu_in=True)          # ReLU applied while the hidden activations are split
-    y16, y32 = add_ln(g, xf, gamma, beta)
+    if d_mid is not None:
+        g = linear(dropout(h, d_mid, relu=True), sh, w2, b2)
+    else:
+        g = linear(h, sh, w2, b2, relu_in=True)      # ReLU applied while the hidden activations are split
+    y16, y32 = add_ln(g, xf, gamma, beta, drop=d_res)
     ctx.fp32 = True
     if recording(ctx):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(xf, h, g)
         ctx.f32_cfg = tuple(shape)
+        ctx.f32_drop = (d_res, d_mid)
         ctx.f32_params = (w1, b1, w2, b2, gamma, beta, sh)
         ctx.f32_from_twin, ctx.f32_x_dtype = x32 is not None, x.dtype
     return y16.view(shape), y32.view(shape)
@@ -343,13 +390,21 @@ def ffn_ln_bwd(ctx, dy, dy32):
     shape = ctx.f32_cfg
     w1, b1, w2, b2, gamma, beta, sh = ctx.f32_params
     M, d = xf.shape
+    d_res, d_mid = ctx.f32_drop
     dyt = _total(dy, dy32, (M, d))
-    ds, dgamma, dbeta, db2 = add_ln_bwd(dyt, g, xf, gamma)
-    dw2 = linear_dw(ds, h, relu_x=True)               # g = relu(h) . W2^T + b2
-    da = linear_dx(ds, sh, w2)                        # gradient of relu(h); ReLU's derivative is applied where da is consumed
-    dw1 = linear_dw(da, xf, mask=h)
-    db1 = colsum(da, mask=h)
-    dx = linear_dx(da, sh, w1, mask=h, into=ds)
+    ds, dg, dgamma, dbeta, db2 = add_ln_bwd(dyt, g, xf, gamma, drop=d_res)
+    if d_mid is not None:                             # g = drop(relu(h)) . W2^T + b2: the dropped activations are rebuilt, not stored
+        dw2 = linear_dw(dg, dropout(h, d_mid, relu=True, log=False))
+        da = dropout(linear_dx(dg, sh, w2), d_mid, gate=h, log=False)     # * keep / (1 - p) * relu'(h)
+        dw1 = linear_dw(da, xf)
+        db1 = colsum(da)
+        dx = linear_dx(da, sh, w1, into=ds)
+    else:
+        dw2 = linear_dw(dg, h, relu_x=True)           # g = relu(h) . W2^T + b2
+        da = linear_dx(dg, sh, w2)                    # gradient of relu(h); ReLU's derivative is applied where da is consumed
+        dw1 = linear_dw(da, xf, mask=h)
+        db1 = colsum(da, mask=h)
+        dx = linear_dx(da, sh, w1, mask=h, into=ds)
     gx = _route(ctx, dx, 0, 1, shape)
     return (gx[0], gx[1], dw1, db1, dw2, db2, dgamma, dbeta) + (None,) * 7
 
@@ -418,7 +473,7 @@ def beta_gate_bwd(ctx, dH, dbeta):
     for is_a, dpool, kpm, x32, gamma, Lx in ((1, da, kpm_a, a32, ga, La), (0, dt, kpm_t, t32, gt, Lt)):
         dY = torch.empty((B * Lx, d), dtype=F32, device=dev)
         _lib.call("hriemo_gate_dy_f32", _ops._p(dH), _ops._p(w), is_a, _ops._p(dpool), _ops._p(kpm), _ops._p(dY), B, L, Lx, d, st)
-        dx, dgam, dbet, _ = add_ln_bwd(dY, x32, None, gamma, want_dbias=False)
+        dx, _, dgam, dbet, _ = add_ln_bwd(dY, x32, None, gamma, want_dbias=False)
         outs.append((dx.view(B, Lx, d), dgam, dbet))
     (dxa, dga, dba), (dxt, dgt, dbt) = outs
     twin_a, twin_t, dt_a, dt_t = ctx.f32_twins

@@ -36,9 +36,10 @@ _SIGS = {
     "hriemo_attn_bwd_colsum_rows": ("iiii", "i"),
     "hriemo_attn_bwd_dq_colsum_rows": ("iiiii", "i"),
     "hriemo_split_bf16x3": ("pliipiip", "i"),
-    "hriemo_attn_fwd_f32": ("plplplplppiiiiip", "i"),
-    "hriemo_attn_probs_f32": ("plplpppiiiiip", "i"),
-    "hriemo_add_ln_f32": ("ppppppiifp", "i"),
+    "hriemo_attn_fwd_f32": ("plplplplppiiiiifQpIip", "i"),
+    "hriemo_attn_probs_f32": ("plplpppiiiiifQpIip", "i"),
+    "hriemo_add_ln_f32": ("ppppppiiffQpIlp", "i"),
+    "hriemo_dropout_f32": ("ppliipfQpIlp", "i"),
     "hriemo_masked_mean_f32": ("pppiiip", "i"),
     "hriemo_gate_input_f32": ("pppiip", "i"),
     "hriemo_sigmoid_beta_f32": ("pppiip", "i"),
@@ -47,8 +48,8 @@ _SIGS = {
     "hriemo_colsum_f32_workspace_bytes": ("ii", "l"),
     "hriemo_colsum_f32": ("pliiplpipp", "i"),
     "hriemo_add_ln_bwd_f32_workspace_bytes": ("ii", "l"),
-    "hriemo_add_ln_bwd_f32": ("ppppppppiiifpp", "i"),
-    "hriemo_attn_bwd_f32": ("plplplplplppplplplpiiiiip", "i"),
+    "hriemo_add_ln_bwd_f32": ("pppppppppiiiffQpIlpp", "i"),
+    "hriemo_attn_bwd_f32": ("plplplplplppplplplpiiiiifQpIip", "i"),
     "hriemo_gate_dpre_f32": ("ppipipppiiip", "i"),
     "hriemo_gate_input_bwd_f32": ("pppppiip", "i"),
     "hriemo_gate_dy_f32": ("ppipppiiiip", "i"),

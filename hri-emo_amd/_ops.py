@@ -1174,7 +1174,7 @@ def unpack_pair(p16, p32, seq):
 class _GradModeAware:
     """Function.forward always runs with grad mode off, and ctx.needs_input_grad mirrors the inputs' requires_grad even under
     torch.no_grad(): a forward that must know whether autograd is RECORDING this call (the fp32 mode saves its activations
-    only then, and refuses to train with dropout) reads the grad mode noted here at apply() time (thread-local)."""
+    only then) reads the grad mode noted here at apply() time (thread-local)."""
 
     @classmethod
     def apply(cls, *args, **kwargs):
@@ -1197,7 +1197,7 @@ class SelfAttnLN(_GradModeAware, torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, p, seed, site, b_off, need_w):
         if precision() == "fp32":
-            return _fp32().self_attn_ln(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p)
+            return _fp32().self_attn_ln(ctx, x, x32, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p, seed, site, b_off)
         _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)
@@ -1277,7 +1277,7 @@ class CrossAttnLN(_GradModeAware, torch.autograd.Function):
         and hands the residual-path gradient of xq to join_q.  slots = (SharedGrad of dQ, SharedGrad of dK|dV): where the attention
         backward writes those gradients, so that they arrive at the projection's backward as column slices of ONE buffer."""
         if precision() == "fp32":
-            return _fp32().cross_attn_ln(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p)
+            return _fp32().cross_attn_ln(ctx, xq, xq32, xkv, w_in, b_in, w_out, b_out, gamma, beta, sh, H, kpm, need_w, p, seed, site, b_off)
         _require_fp32_masters(w_in, b_in, w_out, b_out, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(xq)
@@ -1652,7 +1652,7 @@ class FFNLN(_GradModeAware, torch.autograd.Function):
     def forward(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off, seq=None):
         """seq: the Seq of packed rows (x is [1, N_valid, d]): keys the LayerNorm dropout by the rows of the padded layout"""
         if precision() == "fp32":
-            return _fp32().ffn_ln(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid)
+            return _fp32().ffn_ln(ctx, x, x32, w1, b1, w2, b2, gamma, beta, sh, p, p_mid, seed, site, b_off)
         _require_fp32_masters(w1, b1, w2, b2, gamma, beta)
         ctx.set_materialize_grads(False)      # an unused twin output must arrive as None, not as zeros
         _require_gpu(x)

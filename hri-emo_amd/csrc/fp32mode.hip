@@ -53,16 +53,92 @@ extern "C" int hriemo_split_bf16x3(const float* X, long ldx, int M, int K, void*
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------- LayerNorm(x + g), fp32 in and out
+// ------------------------------------------------------------------------------------------- dropout in the fp32 kernels
+// The same counter hash, keys and element indices as the bf16 kernels (common.h; rowops.hip: key = site_key(seed, site, 0), a = row
+// of the padded layout, b = column; attention.hip: key = site_key(seed, site, (b_offset + b) * H + h), a = query, b = key position),
+// so a model draws the same masks in either precision and tests/hashrng.py replays both.  Evaluated element by element (keep16):
+// these kernels are not the product path's hot loop.
+struct RowDrop {
+  uint32_t thr16; float inv_keep; uint64_t seed; const unsigned long long* seed_dev; uint32_t site; long row_off;
+};
+static RowDrop make_row_drop(float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, long row_off) {
+  const DropCfg c = make_drop(p, seed, site);
+  RowDrop r; r.thr16 = c.thr16; r.inv_keep = c.inv_keep; r.seed = seed; r.seed_dev = seed_dev; r.site = site; r.row_off = row_off;
+  return r;
+}
+struct AttnDrop {
+  uint32_t thr16; float inv_keep; uint64_t seed; const unsigned long long* seed_dev; uint32_t site; int b_offset;
+};
+static AttnDrop make_attn_drop(float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, int b_offset) {
+  const DropCfg c = make_drop(p, seed, site);
+  AttnDrop r; r.thr16 = c.thr16; r.inv_keep = c.inv_keep; r.seed = seed; r.seed_dev = seed_dev; r.site = site; r.b_offset = b_offset;
+  return r;
+}
+__device__ __forceinline__ f32x4 drop4(f32x4 v, uint32_t key, uint32_t a, uint32_t b0, uint32_t thr16, float inv_keep) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = keep16(key, a, b0 + (uint32_t)j, thr16) ? v[j] * inv_keep : 0.f;
+  return v;
+}
+// 0 / inv_keep per element: the factor d drop(g) / d g
+__device__ __forceinline__ f32x4 drop4_factor(uint32_t key, uint32_t a, uint32_t b0, uint32_t thr16, float inv_keep) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = keep16(key, a, b0 + (uint32_t)j, thr16) ? inv_keep : 0.f;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------- element-wise dropout (the FFN's hidden layer)
+// Y = drop(relu ? max(X, 0) : X), times (gate > 0) when a gate matrix is given.  Forward: X = the hidden pre-activations, relu = 1
+// (emotion_decoder.py:57: linear2(dropout(relu(linear1(x))))).  Backward: X = the gradient of the dropped activations, gate = the
+// pre-activations (ReLU's derivative), same site and row offset: the same keep / (1 - p) factors.
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ X, float* __restrict__ Y, long M, int N, int relu,
+                                                          const float* __restrict__ gate, RowDrop dr) {
+  const int nq = N >> 2;
+  const long nv = M * nq;
+  const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, 0u) : 0u;
+  for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long)gridDim.x * blockDim.x) {
+    const long m = v / nq;
+    const int c = (int)(v - m * nq) * 4;
+    f32x4 x = *(const f32x4*)(X + m * N + c);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+    }
+    if (gate != nullptr) {
+      const f32x4 gt = *(const f32x4*)(gate + m * N + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = gt[j] > 0.f ? x[j] : 0.f;
+    }
+    if (dr.thr16 != 0) x = drop4(x, dkey, (uint32_t)(m + dr.row_off), (uint32_t)c, dr.thr16, dr.inv_keep);
+    *(f32x4*)(Y + m * N + c) = x;
+  }
+}
+extern "C" int hriemo_dropout_f32(const float* X, float* Y, long M, int N, int relu, const float* gate, float p, uint64_t seed,
+                                  const unsigned long long* seed_dev, uint32_t site, long row_off, hipStream_t st) {
+  HRIEMO_CHECK(M > 0 && N > 0 && N % 4 == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0 && ((uintptr_t)gate % 16) == 0,
+               "dropout_f32: N=%d must be a multiple of 4 and the matrices 16-byte aligned", N);
+  HRIEMO_CHECK(p >= 0.f && p < 1.f, "dropout_f32: dropout p=%f", (double)p);
+  const RowDrop dr = make_row_drop(p, seed, seed_dev, site, row_off);
+  long g = (M * (N >> 2) + 255) / 256;
+  if (g > 8192) g = 8192;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3((int)g), dim3(256), 0, st, X, Y, M, N, relu, gate, dr);
+  HRIEMO_LAUNCH_CHECK("dropout_f32_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (double)M * N * (gate != nullptr ? 12.0 : 8.0));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm(x + drop(g)), fp32 in and out
 // one wave per row, the row in registers (d <= 64 * 4 * NV4)
 template <int NV4>
 __global__ __launch_bounds__(256) void add_ln_f32_kernel(const float* __restrict__ G, const float* __restrict__ X, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ Y32, bf16_t* __restrict__ Y16, int M,
-                                                         int d, float eps) {
+                                                         int d, float eps, RowDrop dr) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nq = d >> 2;
+  const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, 0u) : 0u;
   f32x4 s[NV4];
   float sum = 0.f;
 #pragma unroll
@@ -71,6 +147,7 @@ __global__ __launch_bounds__(256) void add_ln_f32_kernel(const float* __restrict
     s[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (q < nq) {
       s[c] = *(const f32x4*)(G + row * d + q * 4);
+      if (dr.thr16 != 0) s[c] = drop4(s[c], dkey, (uint32_t)(row + dr.row_off), (uint32_t)(q * 4), dr.thr16, dr.inv_keep);
       if (X != nullptr) s[c] += *(const f32x4*)(X + row * d + q * 4);
       sum += s[c][0] + s[c][1] + s[c][2] + s[c][3];
     }
@@ -100,12 +177,15 @@ __global__ __launch_bounds__(256) void add_ln_f32_kernel(const float* __restrict
 }
 
 extern "C" int hriemo_add_ln_f32(const float* G, const float* X, const float* gamma, const float* beta, float* Y32, void* Y16, int M, int d,
-                                 float eps, hipStream_t st) {
+                                 float eps, float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, long row_off,
+                                 hipStream_t st) {
   HRIEMO_CHECK(M > 0 && d > 0 && d % 4 == 0 && d <= 4096, "add_ln_f32: d=%d must be a multiple of 4, at most 4096", d);
+  HRIEMO_CHECK(p >= 0.f && p < 1.f, "add_ln_f32: dropout p=%f", (double)p);
+  const RowDrop dr = make_row_drop(p, seed, seed_dev, site, row_off);
   hriemo_prof_begin(HP_ROWOPS, st);
   const dim3 grid((M + 3) / 4);
-  if (d <= 1024) hipLaunchKernelGGL((add_ln_f32_kernel<4>), grid, dim3(256), 0, st, G, X, gamma, beta, Y32, (bf16_t*)Y16, M, d, eps);
-  else hipLaunchKernelGGL((add_ln_f32_kernel<16>), grid, dim3(256), 0, st, G, X, gamma, beta, Y32, (bf16_t*)Y16, M, d, eps);
+  if (d <= 1024) hipLaunchKernelGGL((add_ln_f32_kernel<4>), grid, dim3(256), 0, st, G, X, gamma, beta, Y32, (bf16_t*)Y16, M, d, eps, dr);
+  else hipLaunchKernelGGL((add_ln_f32_kernel<16>), grid, dim3(256), 0, st, G, X, gamma, beta, Y32, (bf16_t*)Y16, M, d, eps, dr);
   HRIEMO_LAUNCH_CHECK("add_ln_f32_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (double)M * d * 14.0);
   return 0;
@@ -208,7 +288,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk,
                                                            const float* __restrict__ V, long ldv, float* __restrict__ O, long ldo,
                                                            const uint8_t* __restrict__ kpm, float* __restrict__ lse, int H, int Lq, int Lk,
-                                                           float scale) {
+                                                           float scale, AttnDrop dr) {
   constexpr int LDR = HD + 4;                 // LDS row stride in floats
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = (float*)smem_raw;               // [64][LDR]
@@ -226,6 +306,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
   for (int t = 0; t < HD / 16; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun = -INFINITY, lrun = 0.f;          // running max (shared by the 4 lanes of a query) and THIS lane's partial sum
+  const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, (uint32_t)((dr.b_offset + b) * H + h)) : 0u;
   const float* Kb = K + (long)b * Lk * ldk + h * HD;
   const float* Vb = V + (long)b * Lk * ldv + h * HD;
   for (int k0 = 0; k0 < Lk; k0 += 64) {
@@ -273,8 +354,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = expf(s[n][r] - msafe);
-        s[n][r] = p;
-        lrun += p;
+        lrun += p;                              // the softmax denominator sums every key; dropout acts on the normalised weights
+        s[n][r] = (dr.thr16 == 0 || keep16(dkey, (uint32_t)(q0 + i), (uint32_t)(k0 + 16 * n + 4 * g + r), dr.thr16)) ? p : 0.f;
       }
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -287,7 +368,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
   float l = lrun + __shfl_xor(lrun, 16);
   l += __shfl_xor(l, 32);
   // a query whose keys are all padding: PyTorch's softmax over -inf gives NaN, and so does this (0 * inf)
-  const float inv = 1.f / l;
+  const float inv = (dr.thr16 != 0 ? dr.inv_keep : 1.f) / l;
   if (q0 + i < Lq) {
     float* op = O + ((long)b * Lq + q0 + i) * ldo + h * HD;
 #pragma unroll
@@ -306,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 template <int HD>
 __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float* __restrict__ Q, long ldq, const float* __restrict__ K, long ldk,
                                                              const uint8_t* __restrict__ kpm, const float* __restrict__ lse,
-                                                             float* __restrict__ probs, int H, int Lq, int Lk, float scale) {
+                                                             float* __restrict__ probs, int H, int Lq, int Lk, float scale, AttnDrop dr) {
   constexpr int LDR = HD + 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = (float*)smem_raw;
@@ -337,6 +418,8 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float* __rest
       __syncthreads();
       const float* qp = Q + ((long)b * Lq + q) * ldq + h * HD;
       const float ls = lse[((long)b * H + h) * Lq + q];
+      // (training mode: nn.MultiheadAttention returns the weights AFTER its dropout, so the export drops what the forward dropped)
+      const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, (uint32_t)((dr.b_offset + b) * H + h)) : 0u;
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -344,7 +427,11 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float* __rest
         for (int ks = 0; ks < HD / 4; ++ks)
           s = __builtin_amdgcn_mfma_f32_16x16x4f32(Ks[(16 * n + i) * LDR + 4 * ks + g], qp[4 * ks + g] * scale, s, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[n][r] += expf(s[r] + pad[16 * n + 4 * g + r] - ls);     // lse = -inf (no valid key): NaN, as PyTorch
+        for (int r = 0; r < 4; ++r) {
+          const float pv = expf(s[r] + pad[16 * n + 4 * g + r] - ls);                           // lse = -inf (no valid key): NaN, as PyTorch
+          if (dr.thr16 == 0) acc[n][r] += pv;
+          else acc[n][r] += keep16(dkey, (uint32_t)(q0 + i), (uint32_t)(k0 + 16 * n + 4 * g + r), dr.thr16) ? pv * dr.inv_keep : 0.f * pv;
+        }
       }
     }
     if (q0 + i < Lq) {
@@ -484,17 +571,18 @@ extern "C" int hriemo_colsum_f32(const float* X, long ldx, int M, int N, const f
 }
 
 // ------------------------------------------------------------------------------------------- LayerNorm(x + g) backward, fp32
-// dS = d loss / d (x + g) (= dX = dG without dropout); per-block column partials of dgamma = sum dY * xhat, dbeta = sum dY and
-// dbias = sum dS (the bias of the Linear that produced g).  The row statistics are recomputed (the row is in registers anyway).
+// dS = d loss / d (x + drop(g)) (= dX; = dG too without dropout, else dG = dS * keep / (1 - p) goes to its own matrix); per-block column partials of dgamma = sum dY * xhat, dbeta = sum dY and
+// dbias = sum dG (the bias of the Linear that produced g).  The row statistics are recomputed (the row is in registers anyway).
 template <int NV4>
 __global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __restrict__ dY, const float* __restrict__ G, const float* __restrict__ X,
-                                                             const float* __restrict__ gamma, float* __restrict__ dS, float* __restrict__ part,
-                                                             int M, int d, float eps) {
+                                                             const float* __restrict__ gamma, float* __restrict__ dS, float* __restrict__ dG,
+                                                             float* __restrict__ part, int M, int d, float eps, RowDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;            // [3][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = d >> 2;
   const float invd = 1.f / (float)d;
+  const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, 0u) : 0u;
   f32x4 ag[NV4], ab[NV4], abias[NV4];
 #pragma unroll
   for (int c = 0; c < NV4; ++c) ag[c] = ab[c] = abias[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -507,6 +595,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __rest
       s[c] = dy[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (q < nq) {
         s[c] = *(const f32x4*)(G + row * d + q * 4);
+        if (dr.thr16 != 0) s[c] = drop4(s[c], dkey, (uint32_t)(row + dr.row_off), (uint32_t)(q * 4), dr.thr16, dr.inv_keep);
         if (X != nullptr) s[c] += *(const f32x4*)(X + row * d + q * 4);
         dy[c] = *(const f32x4*)(dY + row * d + q * 4);
         sum += (s[c][0] + s[c][1]) + (s[c][2] + s[c][3]);
@@ -548,8 +637,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __rest
       if (q < nq) {
         f32x4 ds;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ds[j] = rstd * (dy[c][j] - c1 - s[c][j] * c2); abias[c][j] += ds[j]; }
+        for (int j = 0; j < 4; ++j) ds[j] = rstd * (dy[c][j] - c1 - s[c][j] * c2);
         *(f32x4*)(dS + row * d + q * 4) = ds;
+        if (dr.thr16 != 0) {              // the dropped branch's gradient: dG = dS * (keep ? 1 / (1 - p) : 0); the bias sits inside g
+          const f32x4 f = drop4_factor(dkey, (uint32_t)(row + dr.row_off), (uint32_t)(q * 4), dr.thr16, dr.inv_keep);
+          ds *= f;
+          *(f32x4*)(dG + row * d + q * 4) = ds;
+        }
+        abias[c] += ds;
       }
     }
   }
@@ -578,16 +673,20 @@ __global__ __launch_bounds__(256) void add_ln_bwd_f32_kernel(const float* __rest
 }
 static int add_ln_bwd_f32_blocks(int M) { int g = (M + 3) / 4; return g > 512 ? 512 : g; }
 extern "C" long hriemo_add_ln_bwd_f32_workspace_bytes(int M, int d) { return (long)add_ln_bwd_f32_blocks(M) * 3 * d * 4; }
-extern "C" int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dgamma,
-                                     float* dbeta, float* dbias, int accumulate, int M, int d, float eps, float* workspace, hipStream_t st) {
+extern "C" int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dG, float* dgamma,
+                                     float* dbeta, float* dbias, int accumulate, int M, int d, float eps, float p, uint64_t seed,
+                                     const unsigned long long* seed_dev, uint32_t site, long row_off, float* workspace, hipStream_t st) {
   HRIEMO_CHECK(M > 0 && d > 0 && d % 4 == 0 && d <= 1024, "add_ln_bwd_f32: d=%d must be a multiple of 4, at most 1024", d);
+  HRIEMO_CHECK(p >= 0.f && p < 1.f, "add_ln_bwd_f32: dropout p=%f", (double)p);
+  const RowDrop dr = make_row_drop(p, seed, seed_dev, site, row_off);
+  HRIEMO_CHECK(dr.thr16 == 0 || dG != nullptr, "add_ln_bwd_f32: with dropout the gradient of g differs from dS and needs its own output (dG)");
   HRIEMO_CHECK(dY != nullptr && G != nullptr && gamma != nullptr && dS != nullptr && dgamma != nullptr && dbeta != nullptr && workspace != nullptr,
                "add_ln_bwd_f32: missing operand");
   const int nb = add_ln_bwd_f32_blocks(M);
   hriemo_prof_begin(HP_ROWOPS, st);
   // (the row, its gradient and three column accumulators live in registers: 1024 columns -- every BASELINE config -- is what fits
   // without scratch; wider rows are refused above rather than served by a spilling instantiation)
-  hipLaunchKernelGGL((add_ln_bwd_f32_kernel<4>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, workspace, M, d, eps);
+  hipLaunchKernelGGL((add_ln_bwd_f32_kernel<4>), dim3(nb), dim3(256), 3 * d * 4, st, dY, G, X, gamma, dS, dG, workspace, M, d, eps, dr);
   HRIEMO_LAUNCH_CHECK("add_ln_bwd_f32_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (double)M * d * 16.0);
   SegOut so; so.o[0] = dgamma; so.o[1] = dbeta; so.o[2] = dbias;
@@ -608,7 +707,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
                                                               const float* __restrict__ V, long ldv, const float* __restrict__ O, long ldo,
                                                               const float* __restrict__ dO, long lddo, const uint8_t* __restrict__ kpm,
                                                               const float* __restrict__ lse, float* __restrict__ dQ, long lddq,
-                                                              float* __restrict__ delta, int H, int Lq, int Lk, float scale) {
+                                                              float* __restrict__ delta, int H, int Lq, int Lk, float scale, AttnDrop dr) {
   constexpr int LDR = HD + 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Ks = (float*)smem_raw;
@@ -633,6 +732,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
   dl += __shfl_xor(dl, 32);
   const float ls = lse[((long)b * H + h) * Lq + q];
   if (g == 0 && q0 + i < Lq) delta[((long)b * H + h) * Lq + q0 + i] = dl;
+  const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, (uint32_t)((dr.b_offset + b) * H + h)) : 0u;
   f32x4 dq[HD / 16];
 #pragma unroll
   for (int t = 0; t < HD / 16; ++t) dq[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -668,7 +768,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = expf(s[n][r] + pad[16 * n + 4 * g + r] - ls);
-        s[n][r] = p * (dp[n][r] - dl);            // dS^T[key][query]
+        float dpv = dp[n][r];                     // gradient of the DROPPED weight; that of the weight itself is keep / (1 - p) times it
+        if (dr.thr16 != 0) dpv = keep16(dkey, (uint32_t)(q0 + i), (uint32_t)(k0 + 16 * n + 4 * g + r), dr.thr16) ? dpv * dr.inv_keep : 0.f;
+        s[n][r] = p * (dpv - dl);                 // dS^T[key][query]
       }
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -694,7 +796,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
                                                                const float* __restrict__ V, long ldv, const float* __restrict__ dO, long lddo,
                                                                const uint8_t* __restrict__ kpm, const float* __restrict__ lse,
                                                                const float* __restrict__ delta, float* __restrict__ dK, long lddk,
-                                                               float* __restrict__ dV, long lddv, int H, int Lq, int Lk, float scale) {
+                                                               float* __restrict__ dV, long lddv, int H, int Lq, int Lk, float scale,
+                                                               AttnDrop dr) {
   constexpr int LDR = HD + 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* Qs = (float*)smem_raw;
@@ -707,6 +810,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
   const int key = min(k0 + i, Lk - 1);
   const bool kvalid = (k0 + i < Lk) && (kpm == nullptr || kpm[(long)b * Lk + key] == 0);
   const float kpad = kvalid ? 0.f : -INFINITY;
+  const uint32_t dkey = dr.thr16 != 0 ? site_key(eff_seed(dr.seed, dr.seed_dev), dr.site, (uint32_t)((dr.b_offset + b) * H + h)) : 0u;
   const float* kp = K + ((long)b * Lk + key) * ldk + h * HD;
   const float* vp = V + ((long)b * Lk + key) * ldv + h * HD;
   float kf[HD / 4], vf[HD / 4];
@@ -749,8 +853,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_kernel(const float* __re
       for (int r = 0; r < 4; ++r) {
         const int qr = 16 * n + 4 * g + r;
         const float p = expf(s[n][r] + kpad - lss[qr]);       // [query qr][key i]
-        dp[n][r] = p * (dp[n][r] - dls[qr]);                  // dS
-        s[n][r] = p;
+        const float f = dr.thr16 == 0 ? 1.f : (keep16(dkey, (uint32_t)(q0 + qr), (uint32_t)(k0 + i), dr.thr16) ? dr.inv_keep : 0.f);
+        dp[n][r] = p * (f * dp[n][r] - dls[qr]);              // dS
+        s[n][r] = f * p;                                      // the dropped weight: what multiplied V in the forward
       }
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -892,8 +997,10 @@ extern "C" int hriemo_rowdot_bwd_f32(const float* dl, const float* Z, const floa
 
 extern "C" int hriemo_attn_fwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, float* O, long ldo,
                                    const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
-                                   hipStream_t st) {
+                                   float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, int b_offset, hipStream_t st) {
   HRIEMO_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0, "attn_fwd_f32: empty problem");
+  HRIEMO_CHECK(p >= 0.f && p < 1.f, "attn_fwd_f32: dropout p=%f", (double)p);
+  const AttnDrop dr = make_attn_drop(p, seed, seed_dev, site, b_offset);
   HRIEMO_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 &&
                    ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0, "attn_fwd_f32: operands must be 16-byte aligned");
   const float scale = 1.0f / sqrtf((float)head_dim);
@@ -904,7 +1011,7 @@ extern "C" int hriemo_attn_fwd_f32(const float* Q, long ldq, const float* K, lon
     const int lds = (2 * 64 * (HD + 4) + 64) * 4;                                                                                        \
     static bool attr = false;                                                                                                            \
     if (!attr) { hipFuncSetAttribute((const void*)attn_fwd_f32_kernel<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; } \
-    hipLaunchKernelGGL((attn_fwd_f32_kernel<HD>), grid, dim3(256), lds, st, Q, ldq, K, ldk, V, ldv, O, ldo, key_padding_mask, lse, H, Lq, Lk, scale); \
+    hipLaunchKernelGGL((attn_fwd_f32_kernel<HD>), grid, dim3(256), lds, st, Q, ldq, K, ldk, V, ldv, O, ldo, key_padding_mask, lse, H, Lq, Lk, scale, dr); \
   }
   DISPATCH_HD_F32(head_dim, CALL)
 #undef CALL
@@ -914,15 +1021,18 @@ extern "C" int hriemo_attn_fwd_f32(const float* Q, long ldq, const float* K, lon
 }
 
 extern "C" int hriemo_attn_probs_f32(const float* Q, long ldq, const float* K, long ldk, const unsigned char* key_padding_mask,
-                                     const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, hipStream_t st) {
+                                     const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, float p, uint64_t seed,
+                                     const unsigned long long* seed_dev, uint32_t site, int b_offset, hipStream_t st) {
   HRIEMO_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0 && lse != nullptr && probs != nullptr, "attn_probs_f32: empty problem");
+  HRIEMO_CHECK(p >= 0.f && p < 1.f, "attn_probs_f32: dropout p=%f", (double)p);
+  const AttnDrop dr = make_attn_drop(p, seed, seed_dev, site, b_offset);
   HRIEMO_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0, "attn_probs_f32: operands must be 16-byte aligned");
   const float scale = 1.0f / sqrtf((float)head_dim);
   const dim3 grid((Lq + 63) / 64, B);
 #define CALL(HD)                                                                                                                           \
   {                                                                                                                                        \
     const int lds = (64 * (HD + 4) + 64) * 4;                                                                                              \
-    hipLaunchKernelGGL((attn_probs_f32_kernel<HD>), grid, dim3(256), lds, st, Q, ldq, K, ldk, key_padding_mask, lse, probs, H, Lq, Lk, scale); \
+    hipLaunchKernelGGL((attn_probs_f32_kernel<HD>), grid, dim3(256), lds, st, Q, ldq, K, ldk, key_padding_mask, lse, probs, H, Lq, Lk, scale, dr); \
   }
   DISPATCH_HD_F32(head_dim, CALL)
 #undef CALL
@@ -933,8 +1043,10 @@ extern "C" int hriemo_attn_probs_f32(const float* Q, long ldq, const float* K, l
 extern "C" int hriemo_attn_bwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, const float* O, long ldo,
                                    const float* dO, long lddo, const unsigned char* key_padding_mask, const float* lse, float* dQ, long lddq,
                                    float* dK, long lddk, float* dV, long lddv, float* delta, int B, int H, int Lq, int Lk, int head_dim,
-                                   hipStream_t st) {
+                                   float p, uint64_t seed, const unsigned long long* seed_dev, uint32_t site, int b_offset, hipStream_t st) {
   HRIEMO_CHECK(B > 0 && H > 0 && Lq > 0 && Lk > 0 && lse != nullptr && delta != nullptr, "attn_bwd_f32: empty problem");
+  HRIEMO_CHECK(p >= 0.f && p < 1.f, "attn_bwd_f32: dropout p=%f", (double)p);
+  const AttnDrop dr = make_attn_drop(p, seed, seed_dev, site, b_offset);
   HRIEMO_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
                "attn_bwd_f32: leading dimensions must be multiples of 4");
   HRIEMO_CHECK(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)V % 16) == 0 && ((uintptr_t)O % 16) == 0 && ((uintptr_t)dO % 16) == 0 &&
@@ -951,9 +1063,9 @@ extern "C" int hriemo_attn_bwd_f32(const float* Q, long ldq, const float* K, lon
       attr = true;                                                                                                                        \
     }                                                                                                                                     \
     hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<HD>), dim3((Lq + 63) / 64, B * H), dim3(256), lds, st, Q, ldq, K, ldk, V, ldv, O, ldo, dO, lddo, \
-                       key_padding_mask, lse, dQ, lddq, delta, H, Lq, Lk, scale);                                                        \
+                       key_padding_mask, lse, dQ, lddq, delta, H, Lq, Lk, scale, dr);                                                    \
     hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<HD>), dim3((Lk + 63) / 64, B * H), dim3(256), lds + 256, st, Q, ldq, K, ldk, V, ldv, dO, lddo, \
-                       key_padding_mask, lse, delta, dK, lddk, dV, lddv, H, Lq, Lk, scale);                                              \
+                       key_padding_mask, lse, delta, dK, lddk, dV, lddv, H, Lq, Lk, scale, dr);                                          \
   }
   DISPATCH_HD_F32(head_dim, CALL)
 #undef CALL

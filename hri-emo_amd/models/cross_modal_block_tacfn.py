@@ -169,9 +169,10 @@ class CrossModalBlock(nn.Module):
             _ops.fork(side, main)
             for x_ in (t, t32, kpm_t, kpm_a):
                 _ops.share(x_, side)
+            # (audio first at every fork, the reference's order of sub-layers: cross_modal_block_tacfn.py:74-119)
+            a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
             with torch.cuda.stream(side):
                 t_s, t_s32, w_t = self._self(t, t32, self.self_attn_t, self.self_norm_t, kpm_t, p, seed, s[1], need)
-            a_s, a_s32, w_a = self._self(a, a32, self.self_attn_a, self.self_norm_a, kpm_a, p, seed, s[0], need)
             main.wait_stream(side)
             _ops.fork(side, main)
             _ops.share(t_s, main)
@@ -185,13 +186,13 @@ class CrossModalBlock(nn.Module):
                 with torch.cuda.stream(side):
                     kv_t2a = self._kv(a_s, self.attn_t2a, ja)
                 kv_a2t = self._kv(t_s, self.attn_a2t, jt)
+            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
+                                        kv_a2t, ja)
+            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)
             with torch.cuda.stream(side):
                 x, x32, w_t2a = self._cross(t_s, t_s32, kv(a_s, a_s32), self.attn_t2a, self.norm_t1, kpm_t2a, p, seed, s[4], need,
                                             kv_t2a, jt)
                 t_cm, t_cm32 = self._ffn(x, x32, self.ffn_t, self.norm_t2, p, seed, s[5], plan[1] if plan is not None else None)
-            x, x32, w_a2t = self._cross(a_s, a_s32, kv(t_s, t_s32), self.attn_a2t, self.norm_a1, kpm_a2t, p, seed, s[2], need,
-                                        kv_a2t, ja)
-            a_cm, a_cm32 = self._ffn(x, x32, self.ffn_a, self.norm_a2, p, seed, s[3], plan[0] if plan is not None else None)
             main.wait_stream(side)
             for x_ in (t_cm, t_cm32, w_t, w_t2a):
                 _ops.share(x_, main)

@@ -315,17 +315,28 @@ int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const f
  *  - hriemo_attn_fwd_f32 / hriemo_attn_probs_f32: softmax(Q K^T / sqrt(hd) + key padding) V on the fp32 MFMA
  *    (v_mfma_f32_16x16x4_f32), operands and outputs fp32 with row strides; lse = log-sum-exp of the scaled scores per
  *    (batch, head, query), probs = head-averaged probabilities [B,Lq,Lk] (need_weights=True);
- *  - hriemo_add_ln_f32: Y32 (and the bf16 copy Y16 when non-NULL) = LayerNorm(G + X) (X may be NULL), fp32 in and out;
+ *  - hriemo_add_ln_f32: Y32 (and the bf16 copy Y16 when non-NULL) = LayerNorm(drop(G) + X) (X may be NULL), fp32 in and out;
+ *  - dropout (round 4): every fp32 kernel that sits where the reference drops takes (p_drop, seed, seed_dev, site, offset) like its
+ *    bf16 counterpart and draws the SAME mask from the same counter hash (hriemo_add_ln_fwd / hriemo_attn_fwd / hriemo_dropout_bf16):
+ *    attention weights after the softmax (the exported probabilities too, as nn.MultiheadAttention returns them in training mode),
+ *    the sub-layer output before the residual add, and hriemo_dropout_f32 for the FFN's hidden layer: Y = drop(relu ? max(X,0) : X)
+ *    [* (gate > 0) when gate is non-NULL: the backward form, X = gradient, gate = pre-activations]; p_drop = 0 drops nothing;
  *  - gate pieces of models/beta_gate_tacfn.py in fp32: masked mean (:6-24), gate input [a,t,|a-t|,a*t] (:87-89),
  *    w = sigmoid(pre) / beta = mean(w) (:92-95), h = w*a + (1-w)*t over the first L positions (:98-116; A, T are [B,La,d], [B,Lt,d]). */
 int hriemo_split_bf16x3(const float* X, long ldx, int M, int K, void* Y, int layout, int relu, hriemo_stream_t stream);
 int hriemo_attn_fwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, float* O, long ldo,
                         const unsigned char* key_padding_mask, float* lse, int B, int H, int Lq, int Lk, int head_dim,
+                        float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
                         hriemo_stream_t stream);
 int hriemo_attn_probs_f32(const float* Q, long ldq, const float* K, long ldk, const unsigned char* key_padding_mask,
-                          const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, hriemo_stream_t stream);
+                          const float* lse, float* probs, int B, int H, int Lq, int Lk, int head_dim, float p_drop,
+                          unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
+                          hriemo_stream_t stream);
 int hriemo_add_ln_f32(const float* G, const float* X, const float* gamma, const float* beta, float* Y32, void* Y16, int M, int d,
-                      float eps, hriemo_stream_t stream);
+                      float eps, float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
+                      long row_offset, hriemo_stream_t stream);
+int hriemo_dropout_f32(const float* X, float* Y, long M, int N, int relu, const float* gate, float p_drop, unsigned long long seed,
+                       const unsigned long long* seed_dev, unsigned site, long row_offset, hriemo_stream_t stream);
 int hriemo_masked_mean_f32(const float* X, const unsigned char* mask, float* pooled, int B, int L, int d, hriemo_stream_t stream);
 int hriemo_gate_input_f32(const float* a_pool, const float* t_pool, float* gate_in, int B, int d, hriemo_stream_t stream);
 int hriemo_sigmoid_beta_f32(const float* pre, float* w, float* beta, int B, int d, hriemo_stream_t stream);
@@ -346,9 +357,10 @@ int hriemo_fuse_f32(const float* w, const float* A, int La, const float* T, int 
  *    (ta 1, tb 1) on form 2 (6) of dY and form 3 (7) of X (K = 3 (6) M); fp32 output.
  *  - hriemo_colsum_f32: out[n] (+)= sum_m X[m][n] * (mask[m][n] > 0) (bias gradients; mask fp32 [M, ldmask] or NULL), fixed
  *    summation order; workspace >= hriemo_colsum_f32_workspace_bytes.
- *  - hriemo_add_ln_bwd_f32: backward of Y = LayerNorm(G + X) * gamma + beta (X may be NULL): dS = d loss / d (G + X) [M,d]
- *    (= dG = dX), dgamma / dbeta / dbias(= column sums of dS; may be NULL) overwritten or added to (accumulate); the row statistics
- *    are recomputed from G + X.  d <= 1024.  workspace >= hriemo_add_ln_bwd_f32_workspace_bytes(M, d).
+ *  - hriemo_add_ln_bwd_f32: backward of Y = LayerNorm(drop(G) + X) * gamma + beta (X may be NULL): dS = d loss / d (drop(G) + X)
+ *    [M,d] (= dX; = dG as well when p_drop = 0, dG may then be NULL; with dropout dG = dS * keep / (1 - p) is written to its own
+ *    matrix), dgamma / dbeta / dbias (= column sums of dG; may be NULL) overwritten or added to (accumulate); the row statistics
+ *    are recomputed from drop(G) + X.  d <= 1024.  workspace >= hriemo_add_ln_bwd_f32_workspace_bytes(M, d).
  *  - hriemo_attn_bwd_f32: dQ, dK, dV of O = softmax(Q K^T / sqrt(hd) + key padding) V from Q, K, V, O, dO and the forward's lse, on
  *    v_mfma_f32_16x16x4_f32; two kernels (dQ per 64 queries, dK / dV per 64 keys), no atomics, fixed order; delta: scratch
  *    [B, H, Lq] floats (rowsum(dO * O), written by the first kernel for the second).  nn.MultiheadAttention, cross_modal_block_
@@ -364,11 +376,13 @@ long hriemo_colsum_f32_workspace_bytes(int M, int N);
 int hriemo_colsum_f32(const float* X, long ldx, int M, int N, const float* mask, long ldmask, float* out, int accumulate,
                       float* workspace, hriemo_stream_t stream);
 long hriemo_add_ln_bwd_f32_workspace_bytes(int M, int d);
-int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dgamma, float* dbeta,
-                          float* dbias, int accumulate, int M, int d, float eps, float* workspace, hriemo_stream_t stream);
+int hriemo_add_ln_bwd_f32(const float* dY, const float* G, const float* X, const float* gamma, float* dS, float* dG, float* dgamma,
+                          float* dbeta, float* dbias, int accumulate, int M, int d, float eps, float p_drop, unsigned long long seed,
+                          const unsigned long long* seed_dev, unsigned site, long row_offset, float* workspace, hriemo_stream_t stream);
 int hriemo_attn_bwd_f32(const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv, const float* O, long ldo,
                         const float* dO, long lddo, const unsigned char* key_padding_mask, const float* lse, float* dQ, long lddq,
                         float* dK, long lddk, float* dV, long lddv, float* delta, int B, int H, int Lq, int Lk, int head_dim,
+                        float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site, int b_offset,
                         hriemo_stream_t stream);
 int hriemo_gate_dpre_f32(const float* dH, const float* A, int La, const float* T, int Lt, const float* w, const float* dbeta, float* dpre,
                          int B, int L, int d, hriemo_stream_t stream);

@@ -286,14 +286,17 @@ def test_fp32_mode_contract(H):
     with torch.no_grad():
         logits, beta, z = m(cu(g["h_a"]).bfloat16(), cu(g["h_t"]).bfloat16())
     assert z.dtype == torch.bfloat16 and logits.dtype == torch.float32
-    # eval under autograd (dropout inactive) records a graph; TRAIN mode with dropout > 0 is refused loudly -- the fp32 kernels
-    # do not drop, and silently training without dropout would not be the model that was asked for
+    # eval under autograd (dropout inactive) records a graph; TRAIN mode drops (round 4: the fp32 kernels replay the bf16 path's
+    # masks), with or without a recorded graph: another result than eval, and another one on the next call (the seed moves on)
     logits, beta, z = m(cu(g["h_a"]), cu(g["h_t"]))
     assert logits.requires_grad
-    with pytest.raises(NotImplementedError, match="dropout = 0"):
-        m.train()(cu(g["h_a"]), cu(g["h_t"]))
+    m.train()
+    assert m.cross_modal.layers[0].p > 0
+    lt1 = m(cu(g["h_a"]), cu(g["h_t"]))[0]
+    assert lt1.requires_grad and bool(torch.isfinite(lt1).all()) and not torch.equal(lt1.detach(), logits.detach())
     with torch.no_grad():
-        m.train()(cu(g["h_a"]), cu(g["h_t"]))              # nothing recorded: plain forward, allowed
+        lt2 = m(cu(g["h_a"]), cu(g["h_t"]))[0]
+    assert not torch.equal(lt2, lt1.detach()) and not torch.equal(lt2, logits.detach())
 
 
 # ----------------------------------------------------------------------------- training step in fp32 (round 4)
@@ -421,7 +424,8 @@ def test_backward_row_kernels_f32_against_float64(H):
         G64, X64, gam64 = G.double().requires_grad_(True), X.double().requires_grad_(True), gamma.double().requires_grad_(True)
         bet64 = torch.zeros(d, dtype=torch.float64, requires_grad=True)
         torch.nn.functional.layer_norm(G64 + X64, (d,), gam64, bet64, 1e-5).backward(dY.double())
-        ds, dgam, dbet, dbias = _fp32.add_ln_bwd(dY.cuda(), G.cuda(), X.cuda(), gamma.cuda())
+        ds, dg, dgam, dbet, dbias = _fp32.add_ln_bwd(dY.cuda(), G.cuda(), X.cuda(), gamma.cuda())
+        assert dg is ds                                                # no dropout: one gradient for both branches
         for got, ref, n in ((ds, G64.grad, "dS"), (dgam, gam64.grad, "dgamma"), (dbet, bet64.grad, "dbeta"), (dbias, G64.grad.sum(0), "dbias")):
             err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
             assert err <= 2e-5, (M, d, n, err)
@@ -474,3 +478,164 @@ def test_mosei_wrapper_training_step_fp32(H):
     rows = sorted(((_rel(gm[n], gr[n]), n) for n in gr), reverse=True)
     assert rows[0][0] <= GRAD_TOL, rows[:5]
     assert _rel(ga_m, ga_r) <= GRAD_TOL and _rel(gt_m, gt_r) <= GRAD_TOL
+
+
+# ----------------------------------------------------------------------------- dropout in the fp32 kernels (round 4)
+def _word():
+    from hri_emo_amd import _ops
+    return int(_ops.seed_word(torch.device("cuda", 0)).item()) & ((1 << 64) - 1)
+
+
+@pytest.mark.parametrize("M,d,p,row_off", [(300, 768, 0.1, 0), (37, 128, 0.5, 1000), (9, 1024, 0.25, 7)])
+def test_add_ln_f32_with_dropout_forward_and_backward_against_float64(H, M, d, p, row_off):
+    """LayerNorm(x + drop(g)) in fp32: the mask is the bf16 kernels' (tests/hashrng.py rebuilds it from seed, site and the row
+    offset), the forward and every gradient (dX, dG -- now two different matrices --, dgamma, dbeta, dbias = colsum(dG)) match
+    float64 on that mask"""
+    import hashrng
+    from hri_emo_amd import _fp32
+    g = torch.Generator().manual_seed(M + d)
+    G = torch.randn(M, d, generator=g); X = torch.randn(M, d, generator=g); dY = torch.randn(M, d, generator=g)
+    gamma = 1 + 0.1 * torch.randn(d, generator=g); beta = 0.1 * torch.randn(d, generator=g)
+    seed, site = 12345, 7
+    keep = torch.from_numpy(hashrng.rows_mask((seed + _word()) & ((1 << 64) - 1), site, M, d, p, row_off))
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    scale = hashrng.inv_keep(p)
+    G64, X64 = G.double().requires_grad_(True), X.double().requires_grad_(True)
+    gam64, bet64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y64 = torch.nn.functional.layer_norm(X64 + G64 * keep.double() * scale, (d,), gam64, bet64, 1e-5)
+    y64.backward(dY.double())
+    drop = (p, seed, site, row_off)
+    y16, y32 = _fp32.add_ln(G.cuda(), X.cuda(), gamma.cuda(), beta.cuda(), drop=drop)
+    assert float((y32.double().cpu() - y64.detach()).abs().max()) <= 2e-5
+    assert torch.equal(y16, y32.bfloat16())
+    ds, dg, dgam, dbet, dbias = _fp32.add_ln_bwd(dY.cuda(), G.cuda(), X.cuda(), gamma.cuda(), drop=drop)
+    assert dg is not ds
+    for got, ref, n in ((ds, X64.grad, "dX"), (dg, G64.grad, "dG"), (dgam, gam64.grad, "dgamma"), (dbet, bet64.grad, "dbeta"),
+                        (dbias, G64.grad.sum(0), "dbias")):
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= 2e-5, (M, d, n, err)
+    assert bool((dg.cpu()[~keep] == 0).all())                         # a dropped element passes exactly no gradient
+
+
+@pytest.mark.parametrize("M,N,p", [(64, 2048, 0.1), (13, 512, 0.3)])
+def test_dropout_f32_kernel_is_the_hash_mask_exactly(H, M, N, p):
+    """hriemo_dropout_f32: forward drop(relu(x)) and the backward form (gradient * keep / (1 - p) * (pre-activation > 0)) are exact"""
+    import hashrng
+    from hri_emo_amd import _fp32
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(M, N, generator=g); dy = torch.randn(M, N, generator=g)
+    seed, site, off = 99, 21, 640
+    keep = torch.from_numpy(hashrng.rows_mask((seed + _word()) & ((1 << 64) - 1), site, M, N, p, off))
+    scale = torch.tensor(hashrng.inv_keep(p), dtype=torch.float32)
+    drop = (p, seed, site, off)
+    y = _fp32.dropout(x.cuda(), drop, relu=True).cpu()
+    assert torch.equal(y, torch.where(keep, x.clamp_min(0) * scale, torch.zeros(())))
+    back = _fp32.dropout(dy.cuda(), drop, gate=x.cuda(), log=False).cpu()
+    assert torch.equal(back, torch.where(keep & (x > 0), dy * scale, torch.zeros(())))
+    assert torch.equal(_fp32.dropout(x.cuda(), None, relu=True).cpu(), x.clamp_min(0))       # p = 0: ReLU only
+
+
+@pytest.mark.parametrize("B,H_,Lq,Lk,hd,masked,b_off", [(2, 3, 70, 45, 96, True, 0), (1, 2, 130, 130, 64, False, 5), (2, 4, 33, 200, 128, True, 1),
+                                                        (3, 8, 6, 50, 16, True, 0)])
+def test_attention_f32_with_dropout_against_float64(H, B, H_, Lq, Lk, hd, masked, b_off):
+    """fp32 attention forward, exported map and backward with dropout 0.1 on the weights: the mask is the bf16 kernels'
+    (hashrng.attn_mask), outputs and dQ / dK / dV match float64 autograd of (softmax(.) * keep / (1 - p)) V"""
+    import hashrng
+    from hri_emo_amd import _fp32
+    g = torch.Generator().manual_seed(Lq * Lk)
+    d = H_ * hd
+    p, seed, site = 0.1, 4242, 3
+    q = torch.randn(B * Lq, d, generator=g); kv = torch.randn(B * Lk, 2 * d, generator=g); do = torch.randn(B * Lq, d, generator=g)
+    kpm = None
+    if masked:
+        lk = torch.randint(1, Lk + 1, (B,), generator=g)
+        kpm = torch.arange(Lk)[None] >= lk[:, None]
+    keep = torch.from_numpy(hashrng.attn_mask((seed + _word()) & ((1 << 64) - 1), site, B, H_, Lq, Lk, p, b_off)).double()
+    scale = hashrng.inv_keep(p)
+    q64 = q.double().view(B, Lq, H_, hd).transpose(1, 2).requires_grad_(True)
+    k64 = kv[:, :d].double().view(B, Lk, H_, hd).transpose(1, 2).requires_grad_(True)
+    v64 = kv[:, d:].double().view(B, Lk, H_, hd).transpose(1, 2).requires_grad_(True)
+    s = q64 @ k64.transpose(-1, -2) / math.sqrt(hd)
+    if kpm is not None:
+        s = s.masked_fill(kpm[:, None, None, :], float("-inf"))
+    pd = torch.softmax(s, -1) * keep * scale
+    o64 = pd @ v64
+    o64.backward(do.double().view(B, Lq, H_, hd).transpose(1, 2))
+    qc, kvc, doc = q.cuda(), kv.cuda(), do.cuda()
+    k8 = kpm.cuda().view(torch.uint8) if kpm is not None else None
+    drop = (p, seed, site, b_off)
+    o, lse = _fp32.attn(qc, kvc[:, :d], kvc[:, d:], B, H_, Lq, Lk, hd, k8, want_lse=True, drop=drop)
+    back = lambda t, L: t.transpose(1, 2).reshape(B * L, d)          # noqa: E731
+    ro = back(o64.detach(), Lq)
+    assert float((o.double().cpu() - ro).abs().max() / ro.abs().max()) <= 2e-5
+    pr = _fp32.probs(qc, kvc[:, :d], B, H_, Lq, Lk, hd, k8, lse, drop=drop)
+    assert float((pr.double().cpu() - pd.detach().mean(1)).abs().max()) <= 2e-6         # the export is the dropped map, as PyTorch's
+    dq = torch.empty_like(qc); dkv = torch.empty_like(kvc)
+    _fp32.attn_bwd(qc, kvc[:, :d], kvc[:, d:], o, doc, lse, dq, dkv[:, :d], dkv[:, d:], B, H_, Lq, Lk, hd, k8, drop=drop)
+    for got, ref, L, n in ((dq, q64.grad, Lq, "dQ"), (dkv[:, :d], k64.grad, Lk, "dK"), (dkv[:, d:], v64.grad, Lk, "dV")):
+        r = back(ref, L)
+        err = float((got.double().cpu() - r).abs().max() / r.abs().max())
+        assert err <= 2e-5, (n, err)
+
+
+@pytest.mark.parametrize("B,Ta,Tt,d,ne", [(3, 100, 40, 256, 5), (2, 130, 48, 768, 6)])
+def test_fp32_train_step_with_dropout_equals_the_oracle_under_the_same_masks(H, monkeypatch, B, Ta, Tt, d, ne):
+    """The reference trainer's configuration -- fp32, no autocast, TRAIN mode with the modules' dropout 0.1
+    (train_fusion_seq_level_decoder.py:310-334) -- as one exact comparison: the fp32 mode logs every dropout site of its forward
+    (_ops.DROP_LOG: the same sites, keys and order as the bf16 path), tests/hashrng.py rebuilds the keep-masks, the fp32 oracle runs
+    the same step with those masks in place of torch's draws.  Loss, logits, input gradients and every parameter's gradient within
+    north_star's 1e-3."""
+    import numpy as np
+    import hashrng
+    from hri_emo_amd import _ops
+    torch.manual_seed(1234)
+    kw = dict(d_model=d, num_emotions=ne, n_heads=8, dropout=0.1)
+    ref = O.FusionWithEmotionDecoder(**kw).train()
+    m = H.FusionWithEmotionDecoder(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    h_a, h_t, m_a, m_t = _rand_batch(B, Ta, Tt, d, 11)
+    y = (torch.rand(B, ne, generator=torch.Generator().manual_seed(12)) < 0.3).float()
+    word = _word()
+    log = []
+    monkeypatch.setattr(_ops, "DROP_LOG", log)
+    loss_m, logits_m, z_m, ga_m, gt_m, gm = _train_step(m, cu(h_a), cu(h_t), cu(m_a), cu(m_t), cu(y))
+    monkeypatch.setattr(_ops, "DROP_LOG", None)
+    n_attn, n_rows = sum(e[0] == "attn" for e in log), sum(e[0] == "rows" for e in log)
+    assert n_attn == 2 * 4 + 2 * 2 and n_rows == 2 * 6 + 2 * 4, (n_attn, n_rows)       # 2 fusion blocks, 2 decoder layers
+
+    def keep_of(e, shape):
+        seed = (e[1] + word) & ((1 << 64) - 1)
+        if e[0] == "attn":
+            _, _, site, B_, H_, Lq, Lk, p, b_off = e
+            k = hashrng.attn_mask(seed, site, B_, H_, Lq, Lk, p, b_off)
+        else:
+            _, _, site, M, N, p, row_off = e
+            k = hashrng.rows_mask(seed, site, M, N, p, row_off)
+        assert int(np.prod(k.shape)) == int(np.prod(shape)), (e, tuple(shape))
+        return torch.from_numpy(k.reshape(tuple(shape))), hashrng.inv_keep(e[-2] if e[0] == "attn" else e[5])
+
+    cursor = [0]
+
+    def replay_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        e = log[cursor[0]]
+        cursor[0] += 1
+        keep, scale = keep_of(e, x.shape)
+        return x * (keep.to(x.dtype) * scale)
+
+    monkeypatch.setattr(torch.nn.functional, "dropout", replay_dropout)
+    loss_r, logits_r, z_r, ga_r, gt_r, gr = _train_step(ref, h_a, h_t, m_a, m_t, y)
+    assert cursor[0] == len(log)                       # the oracle visited exactly the sites the fp32 mode logged, in order
+    monkeypatch.undo()
+    close(loss_m.reshape(1), loss_r.reshape(1), 1e-5, "loss"); close(logits_m, logits_r, what="logits"); close(z_m, z_r, what="z")
+    rows = sorted(((_rel(gm[n], gr[n]), n) for n in gr), reverse=True)
+    assert rows[0][0] <= GRAD_TOL, ("worst five:", rows[:5])
+    ea, et = _rel(ga_m, ga_r), _rel(gt_m, gt_r)
+    assert ea <= GRAD_TOL and et <= GRAD_TOL, ("input gradients", ea, et)
+    print(f"fp32 dropout-exact step {B}x{Ta}x{Tt}x{d}: worst parameter {rows[0][0]:.2e} ({rows[0][1]}), median {rows[len(rows) // 2][0]:.2e}, "
+          f"d loss / d h_a {ea:.2e}, d loss / d h_t {et:.2e}")
+    # and the masks matter: the oracle with torch's own draws gives another loss
+    torch.manual_seed(78)
+    assert abs(float(_train_step(ref, h_a, h_t, m_a, m_t, y)[0]) - float(loss_r)) > 1e-5
