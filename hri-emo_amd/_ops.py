@@ -532,7 +532,7 @@ def gemm_mode():
 
 
 # ---- arithmetic of the whole path: 'bf16' (product path: bf16 GEMM operands, fp32 accumulate, fp32 residual twins) or 'fp32'
-# (hri-emo_amd/_fp32.py: the reference's fp32 arithmetic to 1e-3, forward and -- with dropout 0 -- backward).  HRIEMO_PRECISION at
+# (hri-emo_amd/_fp32.py: the reference's fp32 arithmetic to 1e-3, forward and backward).  HRIEMO_PRECISION at
 # first use, set_precision().
 PRECISION = None
 
