@@ -70,6 +70,8 @@ _SIGS = {
     "hriemo_pack_rows": ("pppiiiipppp", "i"),
     "hriemo_unpack_rows": ("pppiiippp", "i"),
     "hriemo_dropout_bf16": ("pplifQpIlp", "i"),
+    "hriemo_gemm_ln_supported": ("i", "i"),
+    "hriemo_gemm_ln_fwd": ("iiiplplppppppppppffQpIlpp", "i"),
     "hriemo_expand_rows": ("pppilp", "i"),
     "hriemo_seed_bump": ("pp", "i"),
     "hriemo_rowdot_fwd": ("pppppiip", "i"),

@@ -661,6 +661,37 @@ def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False, want_q
     return linear_fwd(x, wv, b, relu=relu, out_f32=out_f32)
 
 
+FUSE_LN = None             # Linear + bias + dropout + residual + LayerNorm in one launch (csrc/gemm_ln.hip); HRIEMO_FUSE_LN=1
+FUSE_LN_MIN_ROWS = 1024    # a full-row tile is one workgroup per 64 rows: the decoder's M = 384 would use 6 CUs
+
+
+def fuse_ln(M, d):
+    """should this sub-layer's output projection run fused with its LayerNorm?"""
+    global FUSE_LN
+    if FUSE_LN is None:
+        import os
+        FUSE_LN = os.environ.get("HRIEMO_FUSE_LN", "0") == "1"
+    return FUSE_LN and gemm_mode() == "bf16" and M >= FUSE_LN_MIN_ROWS and bool(_lib.lib().hriemo_gemm_ln_supported(d))
+
+
+def proj_add_ln_fwd(a, w16, bias, x, x32, gamma, beta, p, seed, site, row_off, want32, rows=None):
+    """g = a . W^T + bias (bf16, kept for the backward); y = LN(x + drop(g)) -> (g, y, y32 | None, mean, rstd): the results of
+    proj_fwd + add_ln_fwd from ONE kernel (full-row tiles, row statistics reduced across the waves of a workgroup)"""
+    M, K = a.shape
+    d = w16.shape[0]
+    dev = a.device
+    g = torch.empty((M, d), dtype=BF16, device=dev)
+    y = torch.empty((M, d), dtype=BF16, device=dev)
+    y32 = torch.empty((M, d), dtype=torch.float32, device=dev) if want32 else None
+    mean = torch.empty(M, dtype=torch.float32, device=dev)
+    rstd = torch.empty(M, dtype=torch.float32, device=dev)
+    if DROP_LOG is not None and p > 0 and rows is None:
+        DROP_LOG.append(("rows", seed, site, M, d, float(p), row_off))
+    _lib.call("hriemo_gemm_ln_fwd", M, d, K, _p(a), a.stride(0), _p(w16), w16.stride(0), _p(bias), _p(x), _p(x32), _p(gamma), _p(beta),
+              _p(g), _p(y), _p(y32), _p(mean), _p(rstd), _EPS, float(p), seed, _p(seed_word(dev)), site, row_off, _p(rows), _stream())
+    return g, y, y32, mean, rstd
+
+
 def colsum(x, out, accumulate=False):
     M, N = x.shape
     L_ = _lib.lib()
@@ -1218,9 +1249,13 @@ class SelfAttnLN(_GradModeAware, torch.autograd.Function):
         q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         o, lse, mbits = attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, AL, hd, AL) else \
             attn_fwd(q, k, v, AB, H, AL, AL, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
-        g = proj_fwd(Operand(o, mx_of(o)), sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
-                                             want_mx=want_mx_copy(M, d), rows=rows)
+        if fuse_ln(M, d):
+            g, y, y32, mean, rstd = proj_add_ln_fwd(o, w_out16, b_out, x2, x32v, gamma, beta, p, seed, site + 1, b_off * RL, TWIN, rows)
+            mx = []
+        else:
+            g = proj_fwd(Operand(o, mx_of(o)), sh, w_out, w_out16, b_out)
+            y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
+                                                 want_mx=want_mx_copy(M, d), rows=rows)
         probs = attn_probs(q, k, B, H, L, L, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(x2, x32v, qkv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, L, d, H, hd, p, seed, site, b_off)
@@ -1305,9 +1340,13 @@ class CrossAttnLN(_GradModeAware, torch.autograd.Function):
         k, v = kv[:, :d], kv[:, d:]
         o, lse, mbits = attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, want_bits=True, cu=cu) if attn_mask_bits(AB, H, ALk, hd, ALq) else \
             attn_fwd(q, k, v, AB, H, ALq, ALk, hd, kpm, p, seed, site, b_off, cu=cu) + (None,)
-        g = proj_fwd(Operand(o, mx_of(o)), sh, w_out, w_out16, b_out)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
-                                             want_mx=want_mx_copy(B * Lq, d), rows=rows)
+        if fuse_ln(B * Lq, d):
+            g, y, y32, mean, rstd = proj_add_ln_fwd(o, w_out16, b_out, xq2, x32v, gamma, beta, p, seed, site + 1, b_off * RL, TWIN, rows)
+            mx = []
+        else:
+            g = proj_fwd(Operand(o, mx_of(o)), sh, w_out, w_out16, b_out)
+            y, y32, mean, rstd, *mx = add_ln_fwd(g, xq2, gamma, beta, p, seed, site + 1, b_off * RL, x32=x32v, want32=TWIN,
+                                                 want_mx=want_mx_copy(B * Lq, d), rows=rows)
         probs = attn_probs(q, k, B, H, Lq, Lk, hd, kpm, lse, p, seed, site, b_off) if need_w else None
         ctx.save_for_backward(xq2, x32v, xkv2, q, kv, o, lse, g, mean, rstd, w_in16, w_out16, gamma, kpm, mbits)
         ctx.cfg = (B, Lq, Lk, d, H, hd, p, seed, site, b_off)
@@ -1670,13 +1709,17 @@ class FFNLN(_GradModeAware, torch.autograd.Function):
                 DROP_LOG.append(("rows", seed, site + 2, M, h.shape[1], float(p_mid), b_off * L))
             _lib.call("hriemo_dropout_bf16", _p(h), _p(hd_), M, h.shape[1], float(p_mid), seed, _p(seed_word(h.device)),
                       site + 2, b_off * L, _stream())
-        g = proj_fwd(Operand(hd_, mx_of(hd_)), sh, w2, w2_16, b2)
         RL, rows = (seq.L, seq.idx) if seq is not None else (L, None)
         if seq is not None and p_mid > 0:
             raise ValueError("FFNLN: packed rows with a mid-FFN dropout are not built (the encoder's FFNs have none)")
         ctx.rowkey = (RL, rows)
-        y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, rows=rows, x32=x32v, want32=TWIN,
-                                             want_mx=want_mx_copy(M, d))
+        if fuse_ln(M, d):
+            g, y, y32, mean, rstd = proj_add_ln_fwd(hd_, w2_16, b2, x2, x32v, gamma, beta, p, seed, site + 1, b_off * RL, TWIN, rows)
+            mx = []
+        else:
+            g = proj_fwd(Operand(hd_, mx_of(hd_)), sh, w2, w2_16, b2)
+            y, y32, mean, rstd, *mx = add_ln_fwd(g, x2, gamma, beta, p, seed, site + 1, b_off * RL, rows=rows, x32=x32v, want32=TWIN,
+                                                 want_mx=want_mx_copy(M, d))
         ctx.save_for_backward(x2, x32v, h, hd_, g, mean, rstd, w1_16, w2_16, gamma)
         ctx.cfg = (B, L, d, p, p_mid, seed, site, b_off)
         ctx.params = (w1, b1, w2, b2, gamma, beta)

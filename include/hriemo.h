@@ -399,6 +399,19 @@ int hriemo_prof_nclass(void);
 const char* hriemo_prof_name(int cls);
 int hriemo_prof_collect(int cls, double* ms_total, long* launches, double* work);
 
+/* ---- Linear + bias + dropout + residual + LayerNorm in one kernel (round 4, csrc/gemm_ln.hip) ---------------------------------
+ * north_star's "fused bias + LayerNorm + residual epilogue" for the post-LN sites of a fusion layer (cross_modal_block_tacfn.py:
+ * 81,92,105,106,118,119):  G = A[M,K] . W[d,K]^T + bias (bf16; kept because the backward reads it; may be NULL),
+ * Y16 / Y32 (may be NULL) = LayerNorm(X + drop(G)) * gamma + beta, mean / rstd [M] as hriemo_add_ln_fwd leaves them.  X = X32 (fp32
+ * twin) when non-NULL, else X16 (bf16).  A workgroup owns 64 FULL rows (LayerNorm needs them), d in {256, 512, 768}
+ * (hriemo_gemm_ln_supported).  Dropout mask and keys = hriemo_add_ln_fwd(_rows); row_index as there (packed sequences) or NULL.
+ * G is bit-identical to hriemo_gemm_bf16's output, Y to hriemo_add_ln_fwd's within the summation order of the row statistics. */
+int hriemo_gemm_ln_supported(int d);
+int hriemo_gemm_ln_fwd(int M, int d, int K, const void* A, long lda, const void* W, long ldw, const float* bias, const void* X16,
+                       const float* X32, const float* gamma, const float* beta, void* G, void* Y16, float* Y32, float* mean, float* rstd,
+                       float eps, float p_drop, unsigned long long seed, const unsigned long long* seed_dev, unsigned site,
+                       long row_offset, const long long* row_index, hriemo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -475,3 +475,46 @@ def test_rowdot_expand(ops):
     go = torch.randn(B, Ne, d, generator=g).bfloat16().cuda()
     e.backward(go)
     assert (q.grad - go.float().sum(0)).abs().max() <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------- Linear + LayerNorm in one kernel
+@pytest.mark.parametrize("M,d,K,p,twin,mapped", [(1100, 768, 768, 0.1, True, False), (2048, 768, 3072, 0.0, True, False),
+                                                 (130, 256, 128, 0.1, False, False), (64, 512, 96, 0.3, True, False),
+                                                 (333, 768, 768, 0.1, False, True), (4096, 768, 768, 0.1, True, True)])
+def test_gemm_ln_fused_equals_gemm_then_add_ln(ops, M, d, K, p, twin, mapped):
+    """hriemo_gemm_ln_fwd (csrc/gemm_ln.hip: Linear + bias + dropout + residual + LayerNorm on full-row tiles) against the two
+    launches it replaces, hriemo_gemm_bf16 then hriemo_add_ln_fwd(_rows), on the same operands: g (what the backward reads)
+    bit-identical, the same dropout mask (a dropped element changes y by O(1)), y / y32 / mean / rstd equal to the rounding of
+    the row sums (the statistics are reduced in another order: 8 waves x 4 lane groups instead of one wave).  Ragged M (not a
+    multiple of the 64-row tile), K not a multiple of the 32-deep stage, bf16 or fp32 residual, packed-row dropout keys."""
+    g = torch.Generator().manual_seed(M + d + K)
+    A = (0.5 * torch.randn(M, K, generator=g)).bfloat16().cuda()
+    W = (torch.randn(d, K, generator=g) / math.sqrt(K)).bfloat16().cuda()
+    b = (0.1 * torch.randn(d, generator=g)).cuda()
+    X32 = torch.randn(M, d, generator=g).cuda()
+    X16 = X32.bfloat16()
+    gamma = (1 + 0.1 * torch.randn(d, generator=g)).cuda()
+    beta = (0.1 * torch.randn(d, generator=g)).cuda()
+    rows = (torch.randperm(3 * M, generator=g)[:M].sort().values.to(torch.int64).cuda()) if mapped else None
+    seed, site, roff = 13572468, 5, 640
+    x32 = X32 if twin else None
+    g_ref = ops.linear_fwd(A, W, b)
+    y_ref, y32_ref, mean_ref, rstd_ref = ops.add_ln_fwd(g_ref, X16, gamma, beta, p, seed, site, roff, x32=x32, want32=True, rows=rows)
+    g_f, y_f, y32_f, mean_f, rstd_f = ops.proj_add_ln_fwd(A, W, b, X16, x32, gamma, beta, p, seed, site, roff, True, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(g_f, g_ref)
+    scale = max(1.0, float(y32_ref.abs().max()))
+    assert float((y32_f - y32_ref).abs().max()) <= 4e-6 * scale, float((y32_f - y32_ref).abs().max())
+    assert float((y_f.float() - y_ref.float()).abs().max()) <= 2 ** -6 * scale            # one bf16 rounding of O(1..4) values
+    assert float((y_f.float() != y_ref.float()).float().mean()) <= 1e-3                   # and that only where a value sits on a tie
+    assert float((mean_f - mean_ref).abs().max()) <= 1e-6 and float((rstd_f / rstd_ref - 1).abs().max()) <= 1e-5
+    # against fp32 torch math with the host replica of the mask
+    if rows is None and p > 0:
+        keep = torch.from_numpy(hashrng.rows_mask((seed + int(ops.seed_word(torch.device("cuda", 0)).item())) & ((1 << 64) - 1),
+                                                  site, M, d, p, roff)).cuda()
+        s = g_ref.float() * keep * hashrng.inv_keep(p) + (X32 if twin else X16.float())
+        y_t = torch.nn.functional.layer_norm(s, (d,), gamma, beta, 1e-5)
+        assert float((y32_f - y_t).abs().max()) <= 1e-4 * scale
+    # no fp32 twin asked for, no g kept: both optional outputs may be absent
+    _, y_n, y32_n, _, _ = ops.proj_add_ln_fwd(A, W, b, X16, x32, gamma, beta, p, seed, site, roff, False, rows)
+    assert y32_n is None and torch.equal(y_n, y_f)

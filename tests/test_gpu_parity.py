@@ -1323,3 +1323,39 @@ def test_single_label_train_step_vs_oracle(H):
     loss_m, logits_m, gm = step(m, "cuda")
     close(loss_m.reshape(1), loss_r.reshape(1), what="loss"); close(logits_m, logits_r, what="logits")
     assert_per_parameter_grads(gm, gy, gr, exceptions={"beta_gate.mlp.0.weight": 0.15, "beta_gate.mlp.0.bias": 0.15}, what="single_label")
+
+
+@pytest.mark.parametrize("varlen", [False, True])
+def test_fused_linear_layernorm_sites_give_the_same_training_step(H, monkeypatch, varlen):
+    """HRIEMO_FUSE_LN (csrc/gemm_ln.hip, opt-in: measured slower): every encoder sub-layer's output projection +
+    bias + dropout + residual + LayerNorm from ONE kernel.  Same weights, same batch, same dropout seeds, fused vs separate
+    launches: the kernels agree to the rounding of the row statistics, so the whole train-mode step (dropout 0.1, ragged masks;
+    padded and packed rows) must agree far inside the bf16 path's own error -- outputs 2e-3, every parameter's gradient 1e-2."""
+    from hri_emo_amd import _ops
+    torch.manual_seed(1234)
+    m = H.FusionWithEmotionDecoder(d_model=768, num_emotions=6, n_heads=8, dropout=0.1).cuda().train()
+    B, Ta, Tt = 18, 100, 60                      # 1800 / 1080 rows: both branches above the fused path's 1024-row threshold
+    h_a, h_t, m_a, m_t = _rand_batch(B, Ta, Tt, 768, 21)
+    y = (torch.rand(B, 6, generator=torch.Generator().manual_seed(3)) < 0.3).float()
+    args = (cu(h_a), cu(h_t), cu(m_a), cu(m_t), cu(y))
+    H.set_varlen(varlen)
+    try:
+        res = {}
+        for fused in (False, True):
+            monkeypatch.setattr(_ops, "FUSE_LN", fused)
+            calls = []
+            real = _ops.proj_add_ln_fwd
+            monkeypatch.setattr(_ops, "proj_add_ln_fwd", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+            torch.manual_seed(77)                # the dropout seeds come from torch's CPU generator: the same for both runs
+            res[fused] = _train_step(m, *args) + (len(calls),)
+            monkeypatch.setattr(_ops, "proj_add_ln_fwd", real)
+    finally:
+        H.set_varlen(False)
+    (l0, lg0, ga0, gt0, g0, n0), (l1, lg1, ga1, gt1, g1, n1) = res[False], res[True]
+    assert n0 == 0 and n1 == 2 * 6                # six post-LN sites per fusion layer took the fused kernel, the decoder none
+    if not torch.equal(lg0, lg1):                 # (identical seeds are required for a comparison: checked through the outputs)
+        assert float((lg0 - lg1).abs().max()) <= 2e-3 * max(1.0, float(lg0.abs().max())), "logits"
+    assert abs(float(l0) - float(l1)) <= 2e-3 * max(1.0, abs(float(l0)))
+    worst = max((_rel(g1[n], g0[n]), n) for n in g0)
+    assert worst[0] <= 1e-2, worst
+    assert _rel(ga1, ga0) <= 1e-2 and _rel(gt1, gt0) <= 1e-2
