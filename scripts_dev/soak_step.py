@@ -54,5 +54,10 @@ for i in range(n):
                 if p.dim() >= 2 and not bool((g[o:o + k] != ref[o:o + k]).any()):
                     clean.append(names[id(p)])
             print("    matrices that did NOT change:", clean, flush=True)
+pb = getattr(dp, "_pb", None)
+packed = f"varlen {_ops.varlen()}" + (f", {len(pb['graphs'])} bucket graph(s) {sorted(pb['graphs'])}" if pb else "")
+valid = float((~batch[2]).float().mean() + (~batch[3]).float().mean()) / 2
 print(f"STEP SOAK {'CLEAN' if bad_replays == 0 else 'DIRTY'}: {bad_replays} of {n - 1} replays differ ({bad_elems} words) -- "
       f"{(n - 1) * ref.numel():.3g} gradient words compared")
+print(f"STEP SOAK configuration: argv {sys.argv[1:]}, B {B}, ragged {ragged} (valid fraction {valid:.3f}), {packed}, "
+      f"two streams {_ops.side_stream(dev) is not None}, gemm {_ops.gemm_mode()}, precision {_ops.precision()}")
