@@ -493,7 +493,7 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
   };
   if (wave >= NCW) {
     // ------------------------------------------------------------------ loader wave
-    __builtin_amdgcn_s_setprio(3);             // its few instructions go out as soon as they are ready
+    __builtin_amdgcn_s_setprio(3);             // its few instructions go out as soon as they are ready (priority 0: the same step time)
     const int lw = wave - NCW;
     const long astep = TA == 0 ? BK : BK * p.lda, bstep = TB == 0 ? BK : BK * p.ldb;
     const LaneOff aoff = operand_lane<TA, BM, BK>(p.lda, lane), boff = operand_lane<TB, BN, BK>(p.ldb, lane);
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
       load_frags(sa, 0, afA, bfA);
       load_frags(sa, 1, afB, bfB);
       mma(afA, bfA);
-      mma(afB, bfB);
+      mma(afB, bfB);                           // (s_setprio(1) around the clusters: 7.70 vs 7.67 ms per step, not kept)
       // first half's reads up front, the second half's trickle between the first half's MFMAs
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
 #pragma unroll
@@ -758,6 +758,8 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
   // 8.13 -> 7.70 ms on one box); bit 1 of hriemo_gemm_debug_flags switches it off (A/B in one process).
   if ((g_gemm_flags & 2) == 0) {
     if (ta == 1 && (long)K >= 4096 && M >= 768 && N >= 768) return 9;
+    // (wide outputs of the audio branch stay on the 256x256 kernel: 5-8 % ahead alone, and the step is 7.67 ms with it against
+    //  7.74 with config 9 there too)
     if (ta == 0 && M >= 1024 && N >= 256 && !(N >= 2048 && M >= 16384)) return 9;
   }
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip

@@ -270,6 +270,131 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
   leave();
 }
 
+// ------------------------------------------------------------------------------------------------ loader / consumer form
+// gemm.hip's config 9 for MX-fp8 operands (round 4): 256x128 tile, 8 consumer waves + 4 loader waves, and -- because the loaders'
+// stages no longer carry the scale segments -- a ring of THREE 48 KB slots where gemm_mx8_kernel has two (its 2 KB of scales per
+// stage put a third slot 6 KB over the CU's LDS): the operand stream runs two 128-deep steps ahead instead of being drained
+// (`vmcnt(0)`) at every step.  The consumers fetch their scale bytes straight from global memory (read-only inputs, no ring
+// needed: 8 one-byte loads per lane and step, issued one step ahead, the compiler's own vmcnt bookkeeping since consumers issue
+// no LDS-DMA).  Protocol and barrier count as gemm_ws_kernel.
+template <int OUTF32>
+__global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
+  constexpr int BM = 256, BN = 128, NS = 3, WN = 2, NCW = 8, NLW = 4, MT = 4, NTL = 4;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PL = A_BYTES / 1024 / NLW, B_PL = B_BYTES / 1024 / NLW, LPL = A_PL + B_PL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, nxcd = min(8, G), q = G / nxcd, r = G - q * nxcd;
+  const int xcd = blockIdx.x % nxcd, lb = blockIdx.x / nxcd, nx = q + (xcd < r ? 1 : 0);
+  const int before = xcd * q + min(xcd, r);
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int end = (int)((long)tiles * (before + nx) / G), beg = (int)((long)tiles * before / G);
+  const int wg0 = beg + lb;
+  if (wg0 >= end) return;
+  const int nk = p.K / 128;
+  const long lda2 = p.lda / 2, ldb2 = p.ldb / 2;      // operands as "bf16 pairs": a 128-byte fp8 row step = a 64-element bf16 one
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ loader wave
+    __builtin_amdgcn_s_setprio(3);
+    const int lw = wave - NCW;
+    const LaneOff aoff = operand_lane<0, BM, 64>(lda2, lane), boff = operand_lane<0, BN, 64>(ldb2, lane);
+    int iw = wg0, ik = 0, islot = 0;
+    bool more = true;
+    auto issue_next = [&]() -> bool {
+      if (!more) return false;
+      const int tm = iw / p.tiles_n, tn = iw - tm * p.tiles_n;
+      const bf16_t* abase = (const bf16_t*)((const uint8_t*)p.A + (long)tm * BM * p.lda);
+      const bf16_t* bbase = (const bf16_t*)((const uint8_t*)p.B + (long)tn * BN * p.ldb);
+      char* sa = smem + islot * STAGE;
+      stage_operand<0, BM, A_PL, 64>(sa, abase + ik * 64, aoff, lda2, p.M - tm * BM, 64, lw, lane);
+      stage_operand<0, BN, B_PL, 64>(sa + A_BYTES, bbase + ik * 64, boff, ldb2, p.N - tn * BN, 64, lw, lane);
+      islot = (islot + 1 == NS) ? 0 : islot + 1;
+      if (++ik == nk) {
+        iw += nx;
+        ik = 0;
+        if (iw >= end) more = false;
+      }
+      return true;
+    };
+    int pending = 0;
+    if (issue_next()) ++pending;
+    if (issue_next()) ++pending;
+    for (int w = wg0; w < end; w += nx)
+      for (int it = 0; it < nk; ++it) {
+        if (pending >= 2) wait_vmcnt<LPL>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        --pending;
+        if (issue_next()) ++pending;
+      }
+    return;
+  }
+  // -------------------------------------------------------------------- consumer wave
+  const int wm = wave / WN, wn = wave % WN, g = lane >> 4, i = lane & 15;
+  char* scratch = smem + NS * STAGE + wave * 2048;
+  f32x4 acc[MT][NTL];
+  int cur = 0;
+  for (int w = wg0; w < end; w += nx) {
+    TileInfo T;
+    T.slice = 0;
+    const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
+    T.m0 = tm * BM; T.n0 = tn * BN; T.kext = p.K; T.nk = nk;
+    T.abase = nullptr; T.bbase = nullptr; T.a_valid = p.M - T.m0; T.b_valid = p.N - T.n0;
+    // scale bytes of lane (i, g): row (wave tile row + 16 mi + i), k-block 4 ks + g of [K/32][ld] (rows past the matrix edge
+    // read the padding of the scale row: ld is a multiple of 256 by contract)
+    const uint8_t* sap = p.SA + (long)g * p.ldsa + T.m0 + wm * 64 + i;
+    const uint8_t* sbp = p.SB + (long)g * p.ldsb + T.n0 + wn * 64 + i;
+    int sa_c[MT], sb_c[NTL], sa_n[MT], sb_n[NTL];
+    auto load_scales = [&](int ks, int (&sa_)[MT], int (&sb_)[NTL]) {
+      const int kc = ks < nk ? ks : nk - 1;                 // (past the last step: a valid address, the values are not used)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) sa_[mi] = (int)sap[(long)kc * 4 * p.ldsa + mi * 16];
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) sb_[ni] = (int)sbp[(long)kc * 4 * p.ldsb + ni * 16];
+    };
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_scales(0, sa_c, sb_c);
+    auto kstep = [&](int it, int (&sa_)[MT], int (&sb_)[NTL], int (&san)[MT], int (&sbn)[NTL]) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
+      __builtin_amdgcn_s_barrier();
+      load_scales(it + 1, san, sbn);           // next step's scales: in flight under this step's MFMAs
+      const char* st = smem + cur * STAGE;
+      i32x8 fa[MT], fb[NTL];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) fa[mi] = lds_mx_frag(st, wm * 64 + mi * 16 + i, lane);
+#pragma unroll
+      for (int ni = 0; ni < NTL; ++ni) fb[ni] = lds_mx_frag(st + A_BYTES, wn * 64 + ni * 16 + i, lane);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni)         // transposed product: the weight fragment is the A operand, so a lane owns 4 columns of a row
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0, sb_[ni], 0, sa_[mi]);
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+    };
+    for (int it = 0; it < nk; it += 2) {
+      kstep(it, sa_c, sb_c, sa_n, sb_n);
+      if (it + 1 < nk) kstep(it + 1, sa_n, sb_n, sa_c, sb_c);
+      else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) sa_c[mi] = sa_n[mi];
+      }
+    }
+    if (OUTF32) {
+      store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
+    } else {
+      switch (p.epi) {
+        case 1: store_tile<0, 1, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        case 2: store_tile<0, 2, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        case 3: store_tile<0, 3, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+        default: store_tile<0, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ quantiser
 // X[M][K] (bf16 or fp32) -> Xq[M][K] e4m3 bytes + S[K/32][lds] E8M0 bytes.  Per 32-element block: scale 2^e with
 // e = ceil(log2(amax / 448)) (the smallest power of two that brings the block inside e4m3's finite range, so nothing
@@ -317,10 +442,11 @@ struct MxCfg { int bm, bn, wm, wn; };
 static const MxCfg kMx[] = {
     {256, 128, 4, 2},     // 0: 64x64 per wave, 8 waves, one block per CU
     {128, 128, 2, 2},     // 1: 64x64 per wave, 4 waves, two blocks per CU
+    {256, 128, 4, 2},     // 2: config 0's tile on 8 consumer + 4 loader waves, three-slot ring (gemm_mx8_ws_kernel)
 };
 static int g_force_mx = -1;
 extern "C" int hriemo_gemm_mx8_force_config(int cfg) {
-  g_force_mx = (cfg >= 0 && cfg < 2) ? cfg : -1;
+  g_force_mx = (cfg >= 0 && cfg < 3) ? cfg : -1;
   return 0;
 }
 
@@ -341,6 +467,20 @@ static void launch_mx(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_mx8_kernel<OUTF32, BM, BN, WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, q);
 }
 
+template <int OUTF32>
+static void launch_mx_ws(const GemmArgs& a, hipStream_t st) {
+  const int lds = 3 * (256 * 128 + 128 * 128) + 8 * 2048;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_mx8_ws_kernel<OUTF32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const long units = (long)a.tiles_m * a.tiles_n, slots = hriemo_num_cus();
+  GemmArgs q = a;
+  q.sched = nullptr;
+  hipLaunchKernelGGL((gemm_mx8_ws_kernel<OUTF32>), dim3((int)(units < slots ? units : slots)), dim3(768), lds, st, q);
+}
+
 static int gemm_mx8_impl(int M, int N, int K, const void* Aq, long lda, const void* SA, long ldsa, const void* Bq, long ldb,
                          const void* SB, long ldsb, void* C, long ldc, int c_is_f32, const float* bias, int epilogue,
                          const void* aux, long ldaux, void* CQ, long ldcq, void* SC, long ldsc, hipStream_t st) {
@@ -355,7 +495,7 @@ static int gemm_mx8_impl(int M, int N, int K, const void* Aq, long lda, const vo
   HRIEMO_CHECK(epilogue < 2 || (aux != nullptr && ldaux % 8 == 0 && ((uintptr_t)aux % 16) == 0), "gemm_mx8: epilogue 2/3 needs a 16-byte aligned aux");
   HRIEMO_CHECK(!(c_is_f32 && epilogue != 0), "gemm_mx8: fp32 output has no activation epilogue");
   int cfg = g_force_mx;
-  if (cfg < 0) cfg = (M < 1024 || N < 256) ? 1 : 0;
+  if (cfg < 0) cfg = (M < 1024 || N < 256) ? 1 : 2;
   GemmArgs a = {};
   a.M = M; a.N = N; a.K = K;
   a.A = (const bf16_t*)Aq; a.lda = lda; a.B = (const bf16_t*)Bq; a.ldb = ldb;
@@ -369,7 +509,9 @@ static int gemm_mx8_impl(int M, int N, int K, const void* Aq, long lda, const vo
     a.CQ = (uint8_t*)CQ; a.ldcq = ldcq; a.SC = (uint8_t*)SC; a.ldsc = ldsc;
   }
   hriemo_prof_begin(HP_GEMM_MX8, st);
-  if (c_is_f32) {
+  if (cfg == 2) {
+    if (c_is_f32) launch_mx_ws<1>(a, st); else launch_mx_ws<0>(a, st);
+  } else if (c_is_f32) {
     if (cfg == 0) launch_mx<1, 256, 128, 4, 2>(a, st); else launch_mx<1, 128, 128, 2, 2>(a, st);
   } else {
     if (cfg == 0) launch_mx<0, 256, 128, 4, 2>(a, st); else launch_mx<0, 128, 128, 2, 2>(a, st);

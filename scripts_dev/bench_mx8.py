@@ -22,7 +22,7 @@ for (M, N, K) in shapes:
     xq, xs = _ops.quant_mx8(x); wq, ws = _ops.quant_mx8(w)
     tq = timeit(lambda: _ops.quant_mx8(x))
     row = f"M={M:6d} N={N:5d} K={K:5d}  bf16 {t16:7.1f} us {2*M*N*K/t16/1e6:6.0f} TF | quant {tq:6.1f} us ({3*M*K/tq/1e3:5.0f} GB/s)"
-    for cfg in (0, 1):
+    for cfg in (0, 1, 2):
         L.hriemo_gemm_mx8_force_config(cfg)
         t8 = timeit(lambda: _ops.linear_fwd_mx8(xq, xs, wq, ws, b))
         row += f" | mx8 cfg{cfg} {t8:7.1f} us {2*M*N*K/t8/1e6:6.0f} TF"

@@ -69,7 +69,7 @@ MX_SHAPES = [(256, 128, 128), (200, 136, 256), (128, 384, 384), (1024, 768, 768)
              (130, 2304, 768), (8192, 1024, 1024), (300, 264, 640)]
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 @pytest.mark.parametrize("M,N,K", MX_SHAPES)
 def test_gemm_mx8_exact_on_integer_operands(ops, M, N, K, cfg):
     """integers in [-8, 8] survive the quantiser exactly (x * 2^-e is an integer with <= 4 significant bits), so the scaled-MFMA
@@ -96,7 +96,7 @@ def test_gemm_mx8_exact_on_integer_operands(ops, M, N, K, cfg):
         L.hriemo_gemm_mx8_force_config(-1)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 @pytest.mark.parametrize("M,N,K,relu", [(1000, 512, 256, True), (12800, 4096, 1024, True), (300, 128, 640, False), (8192, 1024, 1024, False)])
 def test_gemm_mx8_epilogue_leaves_the_quantised_output(ops, M, N, K, relu, cfg):
     """hriemo_gemm_mx8_q (round 4): the epilogue that stores the bf16 tile also writes its MX-fp8 form -- bytes and E8M0 scales must
