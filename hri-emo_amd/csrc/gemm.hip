@@ -556,27 +556,49 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
     for (int a = 0; a < MT; ++a)
 #pragma unroll
       for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int it = 0; it < T.nk; ++it) {
-      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      const char* sa = smem + cur * STAGE;
-      bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
-      load_frags(sa, 0, afA, bfA);
-      load_frags(sa, 1, afB, bfB);
-      mma(afA, bfA);
-      mma(afB, bfB);                           // (s_setprio(1) around the clusters: 7.70 vs 7.67 ms per step, not kept)
-      // first half's reads up front, the second half's trickle between the first half's MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+    // Software pipeline across the barrier: the second 32-deep half of a position is multiplied AFTER the next barrier, under the
+    // next position's first fragment reads -- every read has a cluster of 16 MFMAs to land under (reading both halves right
+    // after the barrier left all eight consumers reading, and nobody multiplying, at the start of every K-step):
+    //   barrier(s) | read half 0 of s -> A | MFMA(B: half 1 of s-1) | read half 1 of s -> B | MFMA(A) | wait reads | barrier(s+1)
+    // No branch inside the steady body (a fragment set that is conditionally loaded makes hipcc take the bf16x8 vectors apart).
+    bf16x8 afA[MT], bfA[NTL], afB[MT], bfB[NTL];
+    auto interleave = [&]() {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         __builtin_amdgcn_sched_group_barrier(0x008, MT * NTL / 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, (RD + 3) / 4, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, MT * NTL, 0);
+    };
+    {                                          // the tile's first position: nothing pending from before
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sa = smem + cur * STAGE;
+      load_frags(sa, 0, afA, bfA);
+      load_frags(sa, 1, afB, bfB);
+      mma(afA, bfA);
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+      interleave();
       __builtin_amdgcn_sched_barrier(0);
       cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
+    for (int it = 1; it < T.nk; ++it) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* sa = smem + cur * STAGE;
+      load_frags(sa, 0, afA, bfA);
+      mma(afB, bfB);                           // second half of the previous position
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(sa, 1, afB, bfB);
+      mma(afA, bfA);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    mma(afB, bfB);                             // second half of the tile's last position
     if (OUTF32) {
       store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
     } else {
@@ -760,7 +782,7 @@ static int pick_config(int ta, int tb, int M, int N, int K) {
     if (ta == 1 && (long)K >= 4096 && M >= 768 && N >= 768) return 9;
     // (wide outputs of the audio branch stay on the 256x256 kernel: 5-8 % ahead alone, and the step is 7.67 ms with it against
     //  7.74 with config 9 there too)
-    if (ta == 0 && M >= 1024 && N >= 256 && !(N >= 2048 && M >= 16384)) return 9;
+    if (ta == 0 && M >= 1024 && N >= 256 && (!(N >= 2048 && M >= 16384) || (g_gemm_flags & 4))) return 9;
   }
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
   if (M < 1024 || N < 256) {                                                    // decoder / gate sized problems

@@ -1,5 +1,5 @@
-"""GEMM time while another kernel holds some CUs (stand-in for an RCCL collective): static walk vs work queue.
-Run twice: HRIEMO_GEMM_STATIC=1 and unset."""
+"""GEMM time while another kernel holds some CUs (stand-in for an RCCL collective): the work-queue kernels (configs 1 / 2) against
+the loader / consumer kernel (config 9, static walk)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hri_emo_amd
@@ -21,4 +21,7 @@ def timed(fn, hog_blocks):
 for (M, N, K) in [(25600, 768, 768), (25600, 3072, 768), (25600, 768, 3072)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = torch.randn(N, K, device="cuda").bfloat16(); b = torch.randn(N, device="cuda")
     f = lambda: _ops.linear_fwd(A, W, b)
-    print(f"NT {M}x{N}x{K}: alone {timed(f, 0):7.1f} us   with 32 CUs held {timed(f, 32):7.1f} us   with 64 held {timed(f, 64):7.1f} us", flush=True)
+    for cfg in (1, 2, 9):
+        L.hriemo_gemm_force_config(cfg)
+        print(f"NT {M}x{N}x{K} cfg {cfg}: alone {timed(f, 0):7.1f} us   with 32 CUs held {timed(f, 32):7.1f} us   with 64 held {timed(f, 64):7.1f} us", flush=True)
+    L.hriemo_gemm_force_config(-1)
