@@ -661,6 +661,22 @@ def proj_fwd(xop, sh, w, w16, bias, rows=None, relu=False, out_f32=False, want_q
     return linear_fwd(x, wv, b, relu=relu, out_f32=out_f32)
 
 
+_GEMM_CONTENDED = None
+
+
+def gemm_contended(on):
+    """Will other kernels (RCCL collectives) hold CUs while the GEMMs run?  True: the work-queue GEMM kernels (a block that gets
+    its CU late draws fewer tiles); False: the loader / consumer kernels, faster on a chip they have to themselves but walking
+    their tiles statically (profiles/r04_gemm_ws.log: 118 -> 184 us with 32 CUs held against 120 -> 139).  No-op on CPU."""
+    global _GEMM_CONTENDED
+    if _GEMM_CONTENDED is on or not torch.cuda.is_available():
+        return
+    L = _lib.lib()
+    prev = L.hriemo_gemm_debug_flags(1)
+    L.hriemo_gemm_debug_flags((prev | 2) if on else (prev & ~2))
+    _GEMM_CONTENDED = on
+
+
 FUSE_LN = None             # Linear + bias + dropout + residual + LayerNorm in one launch (csrc/gemm_ln.hip); HRIEMO_FUSE_LN=1
 FUSE_LN_MIN_ROWS = 1024    # a full-row tile is one workgroup per 64 rows: the decoder's M = 384 would use 6 CUs
 

@@ -276,6 +276,12 @@ class DataParallelStep:
         return lo, hi
 
     def _fwd_bwd(self, h_a, h_t, m_a, m_t, y, zero=True, scale=None):
+        from . import _ops
+        # collectives launched from the gradient-ready hooks run BESIDE backward (eagerly, or baked into a capture): the GEMMs
+        # then take the work-queue kernels, whose blocks draw fewer tiles when a collective holds their CU late; with the chip to
+        # itself the step takes the loader / consumer kernels, which walk their tiles statically
+        b = self.buckets
+        _ops.gemm_contended(bool(b._hooks) and not b.suspended and b.world > 1)
         if zero:
             self.buckets.zero_grad()
         logits, beta, _ = self.model(h_a, h_t, m_a, m_t)
@@ -283,7 +289,6 @@ class DataParallelStep:
         if scale is not None:
             loss = loss * scale
         if loss.is_cuda and scale is None:
-            from . import _ops
             loss.backward(gradient=_ops.one(loss.device))      # the fused losses skip the multiply by this very tensor
         else:
             loss.backward()
