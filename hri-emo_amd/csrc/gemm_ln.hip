@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void gemm_ln_fwd_kernel(const GemmLnArgs p) {
   for (int mi = 0; mi < MT; ++mi) {
     const long m = (long)m0 + mi * 16 + i;
     const bool rv = m < p.M;
-    eo[mi] = rv ? (unsigned)(m * D + colw) : 0x40000000u;
+    eo[mi] = rv ? (unsigned)(m * D + colw) : 0x20000000u;    // x2 and x4 stay beyond every operand (host: M*D*4 < 2^30), no 32-bit wrap
     const long mc = rv ? m : 0;
     rk[mi] = (uint32_t)(p.row_off + (p.rows != nullptr ? (long)p.rows[mc] : mc));
   }
