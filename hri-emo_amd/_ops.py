@@ -665,15 +665,16 @@ _GEMM_CONTENDED = None
 
 
 def gemm_contended(on):
-    """Will other kernels (RCCL collectives) hold CUs while the GEMMs run?  True: the work-queue GEMM kernels (a block that gets
-    its CU late draws fewer tiles); False: the loader / consumer kernels, faster on a chip they have to themselves but walking
-    their tiles statically (profiles/r04_gemm_ws.log: 118 -> 184 us with 32 CUs held against 120 -> 139).  No-op on CPU."""
+    """Will other kernels (RCCL collectives) hold CUs while the GEMMs run?  True: the loader / consumer GEMM draws its tiles from
+    the per-XCD work queue (with 32 CUs held a 25600x3072x768 launch takes 140 us, 184 on the static walk; 118-124 alone); False
+    (default): static walk, 5-8 % faster per launch on a chip the kernel has to itself, the same step time
+    (profiles/r04_gemm_ws.log).  Bit 3 of hriemo_gemm_debug_flags.  No-op without a GPU."""
     global _GEMM_CONTENDED
     if _GEMM_CONTENDED is on or not torch.cuda.is_available():
         return
     L = _lib.lib()
-    prev = L.hriemo_gemm_debug_flags(1)
-    L.hriemo_gemm_debug_flags((prev | 2) if on else (prev & ~2))
+    prev = L.hriemo_gemm_debug_flags(9)
+    L.hriemo_gemm_debug_flags((prev & ~8) if on else (prev | 8))
     _GEMM_CONTENDED = on
 
 

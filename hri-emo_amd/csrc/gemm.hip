@@ -475,8 +475,29 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
   const int tiles = p.tiles_m * p.tiles_n;
   const long total = (long)tiles * p.splitk;
   const int end = (int)(total * (before + nx) / G), beg = (int)(total * before / G);
-  const int wg0 = beg + lb;
-  if (wg0 >= end) return;
+  // Work queue (p.sched != nullptr), as gemm_body: the blocks of an XCD draw that XCD's units from one atomic counter, so a block
+  // that gets its CU late (another kernel holds it) draws fewer units.  Twelve waves have to agree on the ids and there is no LDS
+  // left for a mailbox -- but consumer wave 0's epilogue scratch is idle while the tile's K loop runs: during tile t wave 0
+  // (lane 0) draws the id of tile t+2 and, in front of the barrier of the tile's last-but-one position, writes the id of tile
+  // t+1 (drawn one tile earlier) into the first word of that scratch; every wave reads it right behind that barrier -- exactly
+  // when the loaders are about to issue tile t+1's first stage -- and the barrier of the last position then separates all
+  // reads from wave 0's next epilogue.  (Every unit has >= 2 K-steps: host.)
+  const bool dyn = p.sched != nullptr;
+  unsigned* const qctr = p.sched + xcd;
+  int* const qslot = (int*)(smem + NS * STAGE);
+  // A block's FIRST unit is its static one (beg + lb: the operand stream starts at once, no round trip to the counter in front
+  // of it); the counter hands out the units from beg + nx on.
+  const int wg0 = beg + lb, wg1 = wg0 + nx;              // (wg1: the static walk's second unit; the queue draws its own)
+  auto leave = [&]() {                                    // every block, exactly once (its thread 0), on its way out
+    if (dyn && tid == 0) {
+      const unsigned done = atomicAdd(p.sched + 8, 1u);
+      if (done == gridDim.x - 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __hip_atomic_store(p.sched + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (wg0 >= end) { leave(); return; }
   auto decode = [&](int w) {
     TileInfo t;
     t.slice = w / tiles;
@@ -497,34 +518,42 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
     const int lw = wave - NCW;
     const long astep = TA == 0 ? BK : BK * p.lda, bstep = TB == 0 ? BK : BK * p.ldb;
     const LaneOff aoff = operand_lane<TA, BM, BK>(p.lda, lane), boff = operand_lane<TB, BN, BK>(p.ldb, lane);
-    int iw = wg0, ik = 0, islot = 0;
-    bool more = true;
-    TileInfo IT = decode(iw);
+    int ik = 0, islot = 0;
+    int known_next = dyn ? end : wg1;          // id of the tile after the one being handed over (queue: read at its position nk-2)
+    bool more = true, crossed = false;         // crossed: the issue cursor has left its tile; the next id is decoded lazily
+    TileInfo IT = decode(wg0);
     auto issue_next = [&]() -> bool {
+      if (crossed) {                           // (only now is the next id certain to have been read)
+        crossed = false;
+        if (known_next < end) IT = decode(known_next); else more = false;
+      }
       if (!more) return false;
       char* sa = smem + islot * STAGE;
       const int krem = IT.kext - ik * BK;
       stage_operand<TA, BM, A_PL, BK>(sa, IT.abase + ik * astep, aoff, p.lda, IT.a_valid, krem, lw, lane);
       stage_operand<TB, BN, B_PL, BK>(sa + A_BYTES, IT.bbase + ik * bstep, boff, p.ldb, IT.b_valid, krem, lw, lane);
       islot = (islot + 1 == NS) ? 0 : islot + 1;
-      if (++ik == IT.nk) {
-        iw += nx;
-        ik = 0;
-        if (iw < end) IT = decode(iw); else more = false;
-      }
+      if (++ik == IT.nk) { ik = 0; crossed = true; }
       return true;
     };
     int pending = 0;                           // positions issued and not yet handed over
     if (issue_next()) ++pending;
     if (issue_next()) ++pending;
-    for (int w = wg0; w < end; w += nx) {
+    for (int w = wg0; w < end;) {
       const int nk = decode(w).nk;
       for (int it = 0; it < nk; ++it) {
         if (pending >= 2) wait_vmcnt<LPL>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (dyn && it == nk - 2) {             // the id of the next tile has just been published
+          const int v = *(LDS_PTR(const int))qslot;
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          known_next = __builtin_amdgcn_readfirstlane(v);
+        }
         --pending;
         if (issue_next()) ++pending;
       }
+      w = known_next;
+      if (!dyn) known_next = w + nx;
     }
     return;
   }
@@ -550,7 +579,13 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
   };
   constexpr int RD = (TA == 0 ? 1 : 2) * MT + (TB == 0 ? 1 : 2) * NTL;     // ds_read instructions per fragment set
   int cur = 0;
-  for (int w = wg0; w < end; w += nx) {
+  const bool drawer = dyn && wave == 0;        // consumer wave 0 (lane 0) draws and publishes the ids
+  // `drawn` (lane 0 of wave 0): the id published during the CURRENT tile; it is overwritten by the draw at the end of the tile's
+  // loop, i.e. after its use -- no copy in between, so the only wait on an atomic's return sits at the publish point, most of
+  // a tile after the draw (a copy right after the epilogue made wave 0 drain its epilogue stores first, and every barrier with it)
+  int drawn = end, nextv = dyn ? end : wg1;
+  if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);     // the block's second unit, needed at tile 0's position nk-2
+  for (int w = wg0; w < end;) {
     const TileInfo T = decode(w);
 #pragma unroll
     for (int a = 0; a < MT; ++a)
@@ -570,9 +605,11 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
       }
     };
     {                                          // the tile's first position: nothing pending from before
+      if (drawer && T.nk == 2 && lane == 0) qslot[0] = drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if (dyn && T.nk == 2) nextv = *(LDS_PTR(const int))qslot;
       const char* sa = smem + cur * STAGE;
       load_frags(sa, 0, afA, bfA);
       load_frags(sa, 1, afB, bfB);
@@ -583,9 +620,11 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
       cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
     for (int it = 1; it < T.nk; ++it) {
+      if (drawer && it == T.nk - 2 && lane == 0) qslot[0] = drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      if (dyn && it == T.nk - 2) nextv = *(LDS_PTR(const int))qslot;
       const char* sa = smem + cur * STAGE;
       load_frags(sa, 0, afA, bfA);
       mma(afB, bfB);                           // second half of the previous position
@@ -599,6 +638,9 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     mma(afB, bfB);                             // second half of the tile's last position
+    // the id of the tile after next: drawn here so that the atomic's round trip passes under the epilogue (drawn at the top of
+    // the tile, hipcc parked wave 0 -- and with it every barrier -- on the returning value: 44.8 vs 38.7 us on 25600x768x768)
+    if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);
     if (OUTF32) {
       store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
     } else {
@@ -609,7 +651,10 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
         default: store_tile<0, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
       }
     }
+    w = __builtin_amdgcn_readfirstlane(nextv);
+    nextv = dyn ? end : w + nx;
   }
+  leave();
 }
 
 // Grouped launch: up to 16 independent problems of one layout / tile configuration, problem blockIdx.y walked statically by its
@@ -677,12 +722,14 @@ int hriemo_num_cus() {
   }
   return n;
 }
-static int g_gemm_flags = 1;        // bit 0: GemmArgs.flags (count the epilogue's stores in the next tile's first wait); bit 1: no config 9
+static int g_gemm_flags = 9;        // bit 0: count the epilogue's stores in the next tile's first wait (configs 0-8); bit 1: no config 9;
+                                    // bit 2: config 9 on wide outputs too; bit 3 (default on; dp.py clears it while collectives run beside backward): config 9 walks its tiles statically
 extern "C" int hriemo_gemm_debug_flags(int flags) {   // tuning hook (A/B in one process): returns the previous value
   const int prev = g_gemm_flags;
   g_gemm_flags = flags;
   return prev;
 }
+int hriemo_gemm_debug_flags_get() { return g_gemm_flags; }
 static int g_force_cfg = -1;
 extern "C" int hriemo_gemm_force_config(int cfg) {   // tuning hook (scripts_dev/bench_gemm.py); -1 = heuristic
   g_force_cfg = (cfg >= 0 && cfg < kNumCfg) ? cfg : -1;
@@ -762,7 +809,7 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
       const long units = (long)a.tiles_m * a.tiles_n * a.splitk;
       const long slots = hriemo_num_cus();
       GemmArgs qa = a;
-      qa.sched = nullptr;                                  // static walk
+      qa.sched = (units > slots && !(a.flags & 8)) ? hriemo_gemm_sched_slot(st) : nullptr;     // (bit 3 of the debug flags: static walk)
       hipLaunchKernelGGL((gemm_ws_kernel<TA, TB, OUTF32>), dim3((int)(units < slots ? units : slots)), dim3(768), wlds, st, qa);
       break;
     }

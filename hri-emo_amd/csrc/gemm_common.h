@@ -32,6 +32,7 @@ struct GemmArgs {
 // host helpers defined in gemm.hip
 unsigned* hriemo_gemm_sched_slot(hipStream_t st);   // work-queue words of the persistent kernels, one slot per (device, stream)
 int hriemo_num_cus();
+int hriemo_gemm_debug_flags_get();                 // current value of the tuning word set by hriemo_gemm_debug_flags
 
 // chunk swizzle of the 64-byte-row image (BK = 32): rows r..r+3 share one 256-B bank row, so the 16-B chunk c of
 // row r is stored at c ^ h((r>>2)&3), h = {0,2,3,1}: conflict-free for the ds_read_b128 lane groups

@@ -290,9 +290,23 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
   const int before = xcd * q + min(xcd, r);
   const int tiles = p.tiles_m * p.tiles_n;
   const int end = (int)((long)tiles * (before + nx) / G), beg = (int)((long)tiles * before / G);
-  const int wg0 = beg + lb;
-  if (wg0 >= end) return;
-  const int nk = p.K / 128;
+  // work queue as gemm_ws_kernel (gemm.hip): first unit static, the rest drawn by consumer wave 0 and handed to the other eleven
+  // waves through the first word of its idle epilogue scratch behind the barrier of the tile's last-but-one position
+  const bool dyn = p.sched != nullptr;
+  unsigned* const qctr = p.sched + xcd;
+  int* const qslot = (int*)(smem + NS * STAGE);
+  const int wg0 = beg + lb, wg1 = wg0 + nx;
+  auto leave = [&]() {
+    if (dyn && tid == 0) {
+      const unsigned done = atomicAdd(p.sched + 8, 1u);
+      if (done == gridDim.x - 1) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) __hip_atomic_store(p.sched + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (wg0 >= end) { leave(); return; }
+  const int nk = p.K / 128;                           // >= 2 when the queue is used (host)
   const long lda2 = p.lda / 2, ldb2 = p.ldb / 2;      // operands as "bf16 pairs": a 128-byte fp8 row step = a 64-element bf16 one
   if (wave >= NCW) {
     // ------------------------------------------------------------------ loader wave
@@ -300,8 +314,14 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
     const int lw = wave - NCW;
     const LaneOff aoff = operand_lane<0, BM, 64>(lda2, lane), boff = operand_lane<0, BN, 64>(ldb2, lane);
     int iw = wg0, ik = 0, islot = 0;
-    bool more = true;
+    int known_next = dyn ? end : wg1;
+    bool more = true, crossed = false;
     auto issue_next = [&]() -> bool {
+      if (crossed) {
+        crossed = false;
+        iw = known_next;
+        if (iw >= end) more = false;
+      }
       if (!more) return false;
       const int tm = iw / p.tiles_n, tn = iw - tm * p.tiles_n;
       const bf16_t* abase = (const bf16_t*)((const uint8_t*)p.A + (long)tm * BM * p.lda);
@@ -310,23 +330,27 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
       stage_operand<0, BM, A_PL, 64>(sa, abase + ik * 64, aoff, lda2, p.M - tm * BM, 64, lw, lane);
       stage_operand<0, BN, B_PL, 64>(sa + A_BYTES, bbase + ik * 64, boff, ldb2, p.N - tn * BN, 64, lw, lane);
       islot = (islot + 1 == NS) ? 0 : islot + 1;
-      if (++ik == nk) {
-        iw += nx;
-        ik = 0;
-        if (iw >= end) more = false;
-      }
+      if (++ik == nk) { ik = 0; crossed = true; }
       return true;
     };
     int pending = 0;
     if (issue_next()) ++pending;
     if (issue_next()) ++pending;
-    for (int w = wg0; w < end; w += nx)
+    for (int w = wg0; w < end;) {
       for (int it = 0; it < nk; ++it) {
         if (pending >= 2) wait_vmcnt<LPL>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (dyn && it == nk - 2) {
+          const int v = *(LDS_PTR(const int))qslot;
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          known_next = __builtin_amdgcn_readfirstlane(v);
+        }
         --pending;
         if (issue_next()) ++pending;
       }
+      w = known_next;
+      if (!dyn) known_next = w + nx;
+    }
     return;
   }
   // -------------------------------------------------------------------- consumer wave
@@ -334,7 +358,10 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
   char* scratch = smem + NS * STAGE + wave * 2048;
   f32x4 acc[MT][NTL];
   int cur = 0;
-  for (int w = wg0; w < end; w += nx) {
+  const bool drawer = dyn && wave == 0;
+  int drawn = end, nextv = dyn ? end : wg1;
+  if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);
+  for (int w = wg0; w < end;) {
     TileInfo T;
     T.slice = 0;
     const int tm = w / p.tiles_n, tn = w - tm * p.tiles_n;
@@ -358,8 +385,10 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
       for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     load_scales(0, sa_c, sb_c);
     auto kstep = [&](int it, int (&sa_)[MT], int (&sb_)[NTL], int (&san)[MT], int (&sbn)[NTL]) {
+      if (drawer && it == nk - 2 && lane == 0) qslot[0] = drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
       __builtin_amdgcn_s_barrier();
+      if (dyn && it == nk - 2) nextv = *(LDS_PTR(const int))qslot;
       load_scales(it + 1, san, sbn);           // next step's scales: in flight under this step's MFMAs
       const char* st = smem + cur * STAGE;
       i32x8 fa[MT], fb[NTL];
@@ -382,6 +411,8 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
         for (int mi = 0; mi < MT; ++mi) sa_c[mi] = sa_n[mi];
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);        // (the read of the next id included)
+    if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);     // the id of the tile after next, under the epilogue
     if (OUTF32) {
       store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
     } else {
@@ -392,7 +423,10 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
         default: store_tile<0, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane); break;
       }
     }
+    w = __builtin_amdgcn_readfirstlane(nextv);
+    nextv = dyn ? end : w + nx;
   }
+  leave();
 }
 
 // ------------------------------------------------------------------------------------------------ quantiser
@@ -477,7 +511,7 @@ static void launch_mx_ws(const GemmArgs& a, hipStream_t st) {
   }
   const long units = (long)a.tiles_m * a.tiles_n, slots = hriemo_num_cus();
   GemmArgs q = a;
-  q.sched = nullptr;
+  q.sched = (units > slots && a.K >= 256 && !(hriemo_gemm_debug_flags_get() & 8)) ? hriemo_gemm_sched_slot(st) : nullptr;   // (>= 2 steps per unit)
   hipLaunchKernelGGL((gemm_mx8_ws_kernel<OUTF32>), dim3((int)(units < slots ? units : slots)), dim3(768), lds, st, q);
 }
 

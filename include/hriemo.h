@@ -64,11 +64,16 @@ int hriemo_gemm_bf16_split(int ta, int tb, int M, int N, int K, const void* A, l
 int hriemo_gemm_colsum_rows(int ta, int tb, int M, int N, int K);
 int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                             const void* aux, long ldaux, float* colsum_partials, hriemo_stream_t stream);
-/* tuning hook: force one of the built tile configurations (-1 = built-in heuristic) */
+/* tuning hook: force one of the built tile configurations (-1 = built-in heuristic); 0-8: work-queue kernels (128x128 ... 32x64
+ * tiles), 9: the loader / consumer kernel (256x128 tile, 8 MFMA waves + 4 waves that only stage operands; round 4, the default for
+ * encoder-sized projections and long weight-gradient reductions) */
 int hriemo_gemm_force_config(int cfg);
-/* Tuning hook (A/B measurements in one process): GemmArgs.flags of every following launch; returns the previous value.  Bit 0
- * (default on): in the 3-stage 256x128 kernel the first K-step after an epilogue counts that epilogue's stores in its retire wait
- * instead of waiting for their acknowledgement (csrc/gemm.hip, `First`). */
+/* Tuning word of every following GEMM launch (default 9); returns the previous value.  Bit 0: in the 3-stage 256x128 kernel the
+ * first K-step after an epilogue counts that epilogue's stores in its retire wait instead of waiting for their acknowledgement;
+ * bit 1: never pick configuration 9; bit 2: configuration 9 also for outputs of >= 2048 columns x >= 16384 rows (default: the
+ * 256x256 kernel); bit 3: configuration 9 (and the MX-fp8 kernel of the same form) walk their tiles statically instead of drawing
+ * them from the per-XCD work queue -- faster on a chip the launch has to itself; hri_emo_amd.dp clears it while collectives run
+ * beside backward (a block whose CU is held late then draws fewer tiles). */
 int hriemo_gemm_debug_flags(int flags);
 
 /* ---- MX-fp8 operand path (BASELINE.json configs[4], "fp8 MFMA path"): the same nn.Linear / in-projection / out-projection

@@ -35,4 +35,4 @@ for rnd in range(5):
 for f in vals:
     r = sorted(res[f])
     print(f"flags {f:3d}: median {r[2]:.3f} ms  (" + " ".join(f"{x:.3f}" for x in res[f]) + ")", flush=True)
-L.hriemo_gemm_debug_flags(1)
+L.hriemo_gemm_debug_flags(9)
