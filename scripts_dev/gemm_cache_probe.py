@@ -20,7 +20,7 @@ for (M, N, K) in [(25600, 768, 768), (25600, 3072, 768), (25600, 768, 3072), (25
     A = torch.randn(M, K, device=dev).bfloat16(); W = torch.randn(N, K, device=dev).bfloat16(); Wt = torch.randn(K, N, device=dev).bfloat16()
     y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     fl = 2.0 * M * N * K
-    for cfg in (1, 2):
+    for cfg in (1, 2, 9):
         L.hriemo_gemm_force_config(cfg)
         for lay, fn_real, fn_alias in (("NT", lambda: _ops.gemm(0, 0, M, N, K, A, K, W, K, y, N), lambda: _ops.gemm(0, 0, M, N, K, A, 0, W, 0, y, N)),
                                         ("NN", lambda: _ops.gemm(0, 1, M, N, K, A, K, Wt, N, y, N), lambda: _ops.gemm(0, 1, M, N, K, A, 0, Wt, 0, y, N))):
