@@ -433,7 +433,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
     T = decode(nwg);
     wg = nwg;
     if (dyn) {
-      if (tid == 0) qslot[0] = drawn;   // wave 0's epilogue is over: its scratch is free until the next one
+      if (tid == 0) qslot[0] = beg + nx + drawn;   // wave 0's epilogue is over: its scratch is free until the next one
       __builtin_amdgcn_s_waitcnt(0xC07F);          // landed before the tile-start barrier publishes it
       parked = true;
     } else {
@@ -580,11 +580,13 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
   constexpr int RD = (TA == 0 ? 1 : 2) * MT + (TB == 0 ? 1 : 2) * NTL;     // ds_read instructions per fragment set
   int cur = 0;
   const bool drawer = dyn && wave == 0;        // consumer wave 0 (lane 0) draws and publishes the ids
-  // `drawn` (lane 0 of wave 0): the id published during the CURRENT tile; it is overwritten by the draw at the end of the tile's
-  // loop, i.e. after its use -- no copy in between, so the only wait on an atomic's return sits at the publish point, most of
-  // a tile after the draw (a copy right after the epilogue made wave 0 drain its epilogue stores first, and every barrier with it)
+  // `drawn` (lane 0 of wave 0): the counter value behind the id published during the CURRENT tile; it is overwritten by the draw
+  // at the end of the tile's loop, i.e. after its use.  The RAW return value is kept and turned into an id only at the publish
+  // point: any arithmetic on it right after the atomic makes hipcc wait for the round trip on the spot (wave 0 late at every
+  // tile's first barrier, and every wave with it: 5-8 % per launch), and a copy after the epilogue made it drain the epilogue's
+  // stores first.  The one wait on the atomic now sits most of a tile after the draw.
   int drawn = end, nextv = dyn ? end : wg1;
-  if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);     // the block's second unit, needed at tile 0's position nk-2
+  if (drawer && lane == 0) drawn = (int)atomicAdd(qctr, 1u);     // the block's second unit, needed at tile 0's position nk-2
   for (int w = wg0; w < end;) {
     const TileInfo T = decode(w);
 #pragma unroll
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
       }
     };
     {                                          // the tile's first position: nothing pending from before
-      if (drawer && T.nk == 2 && lane == 0) qslot[0] = drawn;
+      if (drawer && T.nk == 2 && lane == 0) qslot[0] = beg + nx + drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
       cur = (cur + 1 == NS) ? 0 : cur + 1;
     }
     for (int it = 1; it < T.nk; ++it) {
-      if (drawer && it == T.nk - 2 && lane == 0) qslot[0] = drawn;
+      if (drawer && it == T.nk - 2 && lane == 0) qslot[0] = beg + nx + drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(768) void gemm_ws_kernel(const GemmArgs p) {
     mma(afB, bfB);                             // second half of the tile's last position
     // the id of the tile after next: drawn here so that the atomic's round trip passes under the epilogue (drawn at the top of
     // the tile, hipcc parked wave 0 -- and with it every barrier -- on the returning value: 44.8 vs 38.7 us on 25600x768x768)
-    if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);
+    if (drawer && lane == 0) drawn = (int)atomicAdd(qctr, 1u);
     if (OUTF32) {
       store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
     } else {
@@ -723,7 +725,7 @@ int hriemo_num_cus() {
   return n;
 }
 static int g_gemm_flags = 9;        // bit 0: count the epilogue's stores in the next tile's first wait (configs 0-8); bit 1: no config 9;
-                                    // bit 2: config 9 on wide outputs too; bit 3 (default on; dp.py clears it while collectives run beside backward): config 9 walks its tiles statically
+                                    // bit 2: config 9 for every narrow encoder-sized projection; bit 3 (default on; dp.py clears it while collectives run beside backward): config 9 walks its tiles statically
 extern "C" int hriemo_gemm_debug_flags(int flags) {   // tuning hook (A/B in one process): returns the previous value
   const int prev = g_gemm_flags;
   g_gemm_flags = flags;
@@ -822,14 +824,27 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
 // to give every CU several of them; narrower outputs take 256x128 (forward) or 128x128 at two blocks per CU.
 static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
-  // Round 4: the loader / consumer kernel (config 9) replaces the 256x128 kernel for the encoder-sized projections and the
-  // 256x256 / 128x128 kernels for the long weight-gradient reductions (profiles/r04_gemm_ws.log: 5-17 % per launch, the step
-  // 8.13 -> 7.70 ms on one box); bit 1 of hriemo_gemm_debug_flags switches it off (A/B in one process).
+  // Round 4, from the sweep of profiles/r04_gemm_ws.log (after the work-queue kernels lost their per-tile stall on the id draw,
+  // Makefile GEMM_FLAGS): the loader / consumer kernel (config 9) takes the long weight-gradient reductions and the projections
+  // that are one round of 256x128 tiles or less (text-branch sized), the 256x128 / 256x256 queue kernels everything larger.  Bit 1 of hriemo_gemm_debug_flags: never config 9;
+  // bit 2: config 9 for every encoder-sized projection that is not wide (the selection of the round's middle).
   if ((g_gemm_flags & 2) == 0) {
     if (ta == 1 && (long)K >= 4096 && M >= 768 && N >= 768) return 9;
-    // (wide outputs of the audio branch stay on the 256x256 kernel: 5-8 % ahead alone, and the step is 7.67 ms with it against
-    //  7.74 with config 9 there too)
-    if (ta == 0 && M >= 1024 && N >= 256 && (!(N >= 2048 && M >= 16384) || (g_gemm_flags & 4))) return 9;
+    if (ta == 0 && M >= 1024 && N >= 256) {
+      const bool wide = N >= 2048 && M >= 16384;
+      if (g_gemm_flags & 4) { if (!wide) return 9; }
+      else {
+        // rounds of tiles on the chip x relative time of one tile (scripts_dev/sweep_policy.py, profiles/r04_gemm_ws.log): a
+        // 256x256 tile takes ~1.74 x a 256x128 one; config 9 is ~10 % ahead of config 1 on a single round (no queue traffic,
+        // the loaders hide the cold start) and ~10 % behind on several
+        const long cus = hriemo_num_cus();
+        const long n1 = (long)((M + 255) / 256) * ((N + 127) / 128), n2 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        const long r1 = (n1 + cus - 1) / cus, r2 = (n2 + cus - 1) / cus;
+        const double c1 = (double)r1, c2 = 1.74 * (double)r2, c9 = (double)r1 * (n1 <= cus ? 0.9 : 1.1);
+        if (c9 <= c1 && c9 <= c2) return 9;
+        return c2 < c1 ? 2 : 1;
+      }
+    }
   }
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
   if (M < 1024 || N < 256) {                                                    // decoder / gate sized problems

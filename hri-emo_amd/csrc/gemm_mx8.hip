@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
     T = decode(nwg);
     wg = nwg;
     if (dyn) {
-      if (tid == 0) qslot[0] = drawn;
+      if (tid == 0) qslot[0] = beg + nx + drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);
       parked = true;
     } else {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
   int cur = 0;
   const bool drawer = dyn && wave == 0;
   int drawn = end, nextv = dyn ? end : wg1;
-  if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);
+  if (drawer && lane == 0) drawn = (int)atomicAdd(qctr, 1u);
   for (int w = wg0; w < end;) {
     TileInfo T;
     T.slice = 0;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
       for (int b = 0; b < NTL; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     load_scales(0, sa_c, sb_c);
     auto kstep = [&](int it, int (&sa_)[MT], int (&sb_)[NTL], int (&san)[MT], int (&sbn)[NTL]) {
-      if (drawer && it == nk - 2 && lane == 0) qslot[0] = drawn;
+      if (drawer && it == nk - 2 && lane == 0) qslot[0] = beg + nx + drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of the previous position are in registers
       __builtin_amdgcn_s_barrier();
       if (dyn && it == nk - 2) nextv = *(LDS_PTR(const int))qslot;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(768) void gemm_mx8_ws_kernel(const GemmArgs p) {
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);        // (the read of the next id included)
-    if (drawer && lane == 0) drawn = beg + nx + (int)atomicAdd(qctr, 1u);     // the id of the tile after next, under the epilogue
+    if (drawer && lane == 0) drawn = (int)atomicAdd(qctr, 1u);     // the id of the tile after next, under the epilogue
     if (OUTF32) {
       store_tile<1, 0, MT, NTL>(acc, p, T, scratch, wm, wn, lane);
     } else {

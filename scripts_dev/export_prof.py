@@ -26,7 +26,7 @@ def stats(name, path):
 
 
 def klass(name):
-    m = re.search(r"gemm_kernel<(\d), (\d),", name)
+    m = re.search(r"gemm(?:_ws)?_kernel<(\d), (\d),", name)          # template kernels and the loader / consumer kernel
     if m:
         return {"00": "gemm_bf16_nt", "01": "gemm_bf16_nn", "11": "gemm_bf16_tn"}[m.group(1) + m.group(2)]
     return re.sub(r"\(.*", "", name).replace("void ", "").strip()
