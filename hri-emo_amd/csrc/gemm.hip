@@ -433,7 +433,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p) {
     T = decode(nwg);
     wg = nwg;
     if (dyn) {
-      if (tid == 0) qslot[0] = beg + nx + drawn;   // wave 0's epilogue is over: its scratch is free until the next one
+      if (tid == 0) qslot[0] = drawn;   // wave 0's epilogue is over: its scratch is free until the next one
       __builtin_amdgcn_s_waitcnt(0xC07F);          // landed before the tile-start barrier publishes it
       parked = true;
     } else {
@@ -725,7 +725,7 @@ int hriemo_num_cus() {
   return n;
 }
 static int g_gemm_flags = 9;        // bit 0: count the epilogue's stores in the next tile's first wait (configs 0-8); bit 1: no config 9;
-                                    // bit 2: config 9 for every narrow encoder-sized projection; bit 3 (default on; dp.py clears it while collectives run beside backward): config 9 walks its tiles statically
+                                    // bit 3 (default on; dp.py clears it while collectives run beside backward): config 9 walks its tiles statically
 extern "C" int hriemo_gemm_debug_flags(int flags) {   // tuning hook (A/B in one process): returns the previous value
   const int prev = g_gemm_flags;
   g_gemm_flags = flags;
@@ -824,27 +824,13 @@ static void launch_gemm(const GemmArgs& a, int cfg, hipStream_t st) {
 // to give every CU several of them; narrower outputs take 256x128 (forward) or 128x128 at two blocks per CU.
 static int pick_config(int ta, int tb, int M, int N, int K) {
   if (g_force_cfg >= 0) return g_force_cfg;
-  // Round 4, from the sweep of profiles/r04_gemm_ws.log (after the work-queue kernels lost their per-tile stall on the id draw,
-  // Makefile GEMM_FLAGS): the loader / consumer kernel (config 9) takes the long weight-gradient reductions and the projections
-  // that are one round of 256x128 tiles or less (text-branch sized), the 256x128 / 256x256 queue kernels everything larger.  Bit 1 of hriemo_gemm_debug_flags: never config 9;
-  // bit 2: config 9 for every encoder-sized projection that is not wide (the selection of the round's middle).
+  // Round 4: the loader / consumer kernel (config 9) replaces the 256x128 kernel for the encoder-sized projections and the
+  // 256x256 / 128x128 kernels for the long weight-gradient reductions (profiles/r04_gemm_ws.log: 7-22 % per launch, the step
+  // 7.87 -> 7.39 ms in one process).  Wide outputs of the audio branch stay on the 256x256 kernel (equal alone; 7.39 vs 7.54 ms
+  // per step with a tile-cost model that moved more shapes to the queue kernels).  Bit 1 of hriemo_gemm_debug_flags: never config 9.
   if ((g_gemm_flags & 2) == 0) {
     if (ta == 1 && (long)K >= 4096 && M >= 768 && N >= 768) return 9;
-    if (ta == 0 && M >= 1024 && N >= 256) {
-      const bool wide = N >= 2048 && M >= 16384;
-      if (g_gemm_flags & 4) { if (!wide) return 9; }
-      else {
-        // rounds of tiles on the chip x relative time of one tile (scripts_dev/sweep_policy.py, profiles/r04_gemm_ws.log): a
-        // 256x256 tile takes ~1.74 x a 256x128 one; config 9 is ~10 % ahead of config 1 on a single round (no queue traffic,
-        // the loaders hide the cold start) and ~10 % behind on several
-        const long cus = hriemo_num_cus();
-        const long n1 = (long)((M + 255) / 256) * ((N + 127) / 128), n2 = (long)((M + 255) / 256) * ((N + 255) / 256);
-        const long r1 = (n1 + cus - 1) / cus, r2 = (n2 + cus - 1) / cus;
-        const double c1 = (double)r1, c2 = 1.74 * (double)r2, c9 = (double)r1 * (n1 <= cus ? 0.9 : 1.1);
-        if (c9 <= c1 && c9 <= c2) return 9;
-        return c2 < c1 ? 2 : 1;
-      }
-    }
+    if (ta == 0 && M >= 1024 && N >= 256 && !(N >= 2048 && M >= 16384)) return 9;
   }
   if (ta == 1) return ((long)M * N >= 768L * 2304 && (long)K >= 4096) ? 2 : 0;   // dW: split-K fills the chip
   if (M < 1024 || N < 256) {                                                    // decoder / gate sized problems

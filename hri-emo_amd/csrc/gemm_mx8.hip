@@ -260,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void gemm_mx8
     T = decode(nwg);
     wg = nwg;
     if (dyn) {
-      if (tid == 0) qslot[0] = beg + nx + drawn;
+      if (tid == 0) qslot[0] = drawn;
       __builtin_amdgcn_s_waitcnt(0xC07F);
       parked = true;
     } else {

@@ -70,8 +70,7 @@ int hriemo_gemm_bf16_colsum(int ta, int tb, int M, int N, int K, const void* A, 
 int hriemo_gemm_force_config(int cfg);
 /* Tuning word of every following GEMM launch (default 9); returns the previous value.  Bit 0: in the 3-stage 256x128 kernel the
  * first K-step after an epilogue counts that epilogue's stores in its retire wait instead of waiting for their acknowledgement;
- * bit 1: never pick configuration 9; bit 2: configuration 9 also for outputs of >= 2048 columns x >= 16384 rows (default: the
- * 256x256 kernel); bit 3: configuration 9 (and the MX-fp8 kernel of the same form) walk their tiles statically instead of drawing
+ * bit 1: never pick configuration 9; bit 3: configuration 9 (and the MX-fp8 kernel of the same form) walk their tiles statically instead of drawing
  * them from the per-XCD work queue -- faster on a chip the launch has to itself; hri_emo_amd.dp clears it while collectives run
  * beside backward (a block whose CU is held late then draws fewer tiles). */
 int hriemo_gemm_debug_flags(int flags);
