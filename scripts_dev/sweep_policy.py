@@ -8,7 +8,7 @@ L = _lib.lib()
 dev = torch.device("cuda", 0)
 
 
-def timeit(fn, reps=20):
+def timeit(fn, reps=40):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
