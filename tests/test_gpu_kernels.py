@@ -518,3 +518,36 @@ def test_gemm_ln_fused_equals_gemm_then_add_ln(ops, M, d, K, p, twin, mapped):
     # no fp32 twin asked for, no g kept: both optional outputs may be absent
     _, y_n, y32_n, _, _ = ops.proj_add_ln_fwd(A, W, b, X16, x32, gamma, beta, p, seed, site, roff, False, rows)
     assert y32_n is None and torch.equal(y_n, y_f)
+
+
+# ------------------------------------------------------------------------------------------- loader / consumer GEMM, both walks
+@pytest.mark.parametrize("flags", [9, 1])
+def test_gemm_loader_consumer_kernel_static_walk_and_work_queue(ops, flags):
+    """Configuration 9 (gemm_ws_kernel: 8 MFMA waves + 4 waves that only stage operands) on problems with several rounds of
+    tiles, with the static walk (hriemo_gemm_debug_flags bit 3 set: the N = 1 default) and with the per-XCD work queue (bit 3
+    clear: what dp.py selects while collectives run beside backward; ids handed from consumer wave 0 to the other eleven waves
+    through its idle epilogue scratch): NT with bias / ReLU, NN with the residual epilogue, the fp32 weight-gradient layout with
+    split-K, ragged edges, units with two K-steps (the queue's shortest hand-over).  Exact on integers -- a tile that is skipped,
+    computed twice or started from a stale id shows at once."""
+    from hri_emo_amd import _lib
+    L = _lib.lib()
+    prev = L.hriemo_gemm_debug_flags(flags)
+    L.hriemo_gemm_force_config(9)
+    try:
+        for (M, N, K) in [(25600, 768, 768), (70000, 768, 128), (66000, 264, 192), (5000, 776, 1024), (40000, 1536, 256)]:
+            A, W, b = ints((M, K), seed=1), ints((N, K), seed=2), ints((N,), seed=3)
+            Ad, Wd = A.cuda().bfloat16(), W.cuda().bfloat16()
+            ref = A @ W.t() + b
+            assert torch.equal(ops.linear_fwd(Ad, Wd, b.cuda()).float().cpu(), ref.bfloat16().float()), (flags, "NT", M, N, K)
+            assert torch.equal(ops.linear_fwd(Ad, Wd, b.cuda(), relu=True).float().cpu(), ref.clamp(min=0).bfloat16().float()), (flags, "NT relu")
+            dY, W2, R = ints((M, N), seed=5), ints((N, K), seed=6), ints((M, K), seed=7)
+            dx = ops.linear_dx(dY.cuda().bfloat16(), W2.cuda().bfloat16(), epi=3, aux=R.cuda().bfloat16())
+            assert torch.equal(dx.float().cpu(), (dY @ W2 + R).bfloat16().float()), (flags, "NN + aux", M, N, K)
+        for (Nout, Kout, Mred) in [(768, 768, 25600), (3072, 768, 8192), (776, 264, 12000)]:
+            dY, X = ints((Mred, Nout), -2, 3, seed=8), ints((Mred, Kout), -2, 3, seed=9)
+            out = torch.full((Nout, Kout), 3.0, device="cuda")
+            ops.linear_dw(dY.cuda().bfloat16(), X.cuda().bfloat16(), out, True)
+            assert torch.equal(out.cpu(), dY.t() @ X + 3.0), (flags, "TN", Nout, Kout, Mred)
+    finally:
+        L.hriemo_gemm_force_config(-1)
+        L.hriemo_gemm_debug_flags(prev)

@@ -96,6 +96,27 @@ def test_gemm_mx8_exact_on_integer_operands(ops, M, N, K, cfg):
         L.hriemo_gemm_mx8_force_config(-1)
 
 
+def test_gemm_mx8_loader_consumer_kernel_work_queue(ops):
+    """gemm_mx8_ws_kernel on several rounds of tiles with the per-XCD work queue (hriemo_gemm_debug_flags bit 3 clear) and with
+    the static walk: exact on integers (see test_gemm_mx8_exact_on_integer_operands)"""
+    from hri_emo_amd import _lib
+    L = _lib.lib()
+    L.hriemo_gemm_mx8_force_config(2)
+    for flags in (1, 9):
+        prev = L.hriemo_gemm_debug_flags(flags)
+        try:
+            for (M, N, K) in [(25600, 1024, 256), (40000, 768, 512), (9000, 2056, 384)]:
+                A, W, b = ints((M, K), seed=1), ints((N, K), -6, 7, seed=2), ints((N,), -3, 4, seed=3)
+                ref = A @ W.t() + b
+                aq, as_ = ops.quant_mx8(A.cuda().bfloat16())
+                wq, ws = ops.quant_mx8(W.cuda())
+                y = ops.linear_fwd_mx8(aq, as_, wq, ws, b.cuda())
+                assert torch.equal(y.float().cpu(), ref.bfloat16().float()), (flags, M, N, K)
+        finally:
+            L.hriemo_gemm_debug_flags(prev)
+    L.hriemo_gemm_mx8_force_config(-1)
+
+
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 @pytest.mark.parametrize("M,N,K,relu", [(1000, 512, 256, True), (12800, 4096, 1024, True), (300, 128, 640, False), (8192, 1024, 1024, False)])
 def test_gemm_mx8_epilogue_leaves_the_quantised_output(ops, M, N, K, relu, cfg):
