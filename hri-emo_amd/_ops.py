@@ -97,7 +97,41 @@ def side_stream(device):
     return s
 
 
-CAPTURE_ORIGIN = None      # the stream dp.DataParallelStep.capture() captures on (None outside a capture)
+class StepContext:
+    """State of ONE model's step in flight -- what used to be module globals, so that two models (or two DataParallelSteps) in one
+    process cannot see each other's capture flag, packed plan or gradient-join scope.  dp.DataParallelStep owns one and installs
+    it around capture() / step() (use_context); models used on their own run on the module's default context.
+      capturing      set by DataParallelStep.capture(): weight shadows are re-cast inside the graph, buffers are kept, not freed
+      capture_origin the stream the capture runs on (every helper-stream fork must start there: fork())
+      seq_override   (Seq audio, Seq text) injected for the bucketed packed graphs (models/cross_modal_block_tacfn.py)
+      join_scope     > 0 inside a forward whose outputs ALL depend on both encoder branches (grad_join)
+      half_reports   id(parameter) -> SharedProjFn nodes that have written their half of its gradient in this step"""
+    __slots__ = ("capturing", "capture_origin", "seq_override", "join_scope", "half_reports")
+
+    def __init__(self):
+        self.capturing, self.capture_origin, self.seq_override, self.join_scope, self.half_reports = False, None, None, 0, {}
+
+
+CTX = StepContext()        # the context in force
+
+
+class use_context:
+    """`with use_context(ctx):` -- ctx is the step context in force inside the block (re-entrant: the previous one comes back)"""
+
+    def __init__(self, ctx):
+        self.ctx, self.prev = ctx, None
+
+    def __enter__(self):
+        global CTX
+        self.prev, CTX = CTX, self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        global CTX
+        CTX = self.prev
+        return False
+
+
 
 
 def fork(child, parent):
@@ -105,7 +139,7 @@ def fork(child, parent):
     capture's origin stream: a helper stream forked from an already forked stream (a fork nested inside a fork) makes
     hipStreamEndCapture segfault on ROCm 7.2 (gpurun_out/seg.log of round 2) -- raw HIP events or torch streams
     alike -- so that shape is refused here, as a Python exception, before anything reaches the runtime."""
-    if CAPTURING and CAPTURE_ORIGIN is not None and parent != CAPTURE_ORIGIN and child != CAPTURE_ORIGIN:
+    if CTX.capturing and CTX.capture_origin is not None and parent != CTX.capture_origin and child != CTX.capture_origin:
         raise RuntimeError("hri_emo_amd: a stream was forked from a stream that is itself a fork of the capture stream; ROCm 7.2 "
                            "crashes in hipStreamEndCapture on nested forks -- fork helper streams from the capturing stream only "
                            "(join the side stream back first), or run this step eagerly")
@@ -151,15 +185,13 @@ def new_site_base():
 
 
 _seed_words = {}
-_half_reports = {}         # id(parameter) -> SharedProjFn nodes that have written their half of its gradient in this step
-CAPTURING = False          # set by dp.DataParallelStep.capture(): weight shadows are re-cast inside the graph
 STEP_ID = 0                # bumped at the top of every model step (begin_step): "this shadow was already cast in this step"
 
 
 def begin_step():
     global STEP_ID
     STEP_ID += 1
-    _half_reports.clear()
+    CTX.half_reports.clear()
 
 WEIGHTS_EPOCH = 0          # bumped by anything that rewrites parameter storage behind autograd's back (optim.FusedClipAdamW
                            # updates the flat buffer through raw pointers: p._version and p.data_ptr() do not move)
@@ -226,7 +258,7 @@ class Shadows:
         ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
         # inside a capture every step re-casts (the replayed graph must honour optimizer updates), but only once per step:
         # a shadow prefetched at the top of the step (prefetch()) is not cast again on the decoder's serial chain
-        if (CAPTURING and (ent is None or len(ent) < 3 or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != p.device:
+        if (CTX.capturing and (ent is None or len(ent) < 3 or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != p.device:
             s = ent[1] if ent is not None and ent[1].device == p.device and ent[1].shape == p.shape else \
                 torch.empty(p.shape, dtype=BF16, device=p.device)
             _require_gpu(p)
@@ -250,7 +282,7 @@ class Shadows:
         ent = self._d.get(key)
         ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
         dev = parts[0][0].device
-        if (CAPTURING and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != dev:
+        if (CTX.capturing and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver or ent[1].device != dev:
             rows = sum(r1 - r0 for _, r0, r1 in parts)
             K = parts[0][0].shape[1]
             s = ent[1] if ent is not None and ent[1].device == dev else torch.empty((rows, K), dtype=BF16, device=dev)
@@ -276,8 +308,8 @@ class Shadows:
         vw = tuple((p._version, p.data_ptr()) for p, _, _ in wparts) + (WEIGHTS_EPOCH,)
         vb = tuple((p._version, p.data_ptr()) for p, _, _ in bparts) + (WEIGHTS_EPOCH,)
         dev = wparts[0][0].device
-        stale_w = (CAPTURING and (ew is None or ew[2] != STEP_ID)) or ew is None or ew[0] != vw or ew[1].device != dev
-        stale_b = (CAPTURING and (eb is None or eb[2] != STEP_ID)) or eb is None or eb[0] != vb or eb[1].device != dev
+        stale_w = (CTX.capturing and (ew is None or ew[2] != STEP_ID)) or ew is None or ew[0] != vw or ew[1].device != dev
+        stale_b = (CTX.capturing and (eb is None or eb[2] != STEP_ID)) or eb is None or eb[0] != vb or eb[1].device != dev
         if not (stale_w or stale_b):
             return ew[1], eb[1]
         if not all(p.is_contiguous() for p, _, _ in wparts + bparts):
@@ -313,7 +345,7 @@ class Shadows:
         key = ("catmx",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
         ent = self._d.get(key)
         ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
-        if CAPTURING or ent is None or ent[0] != ver:
+        if CTX.capturing or ent is None or ent[0] != ver:
             rows = sum(r1 - r0 for _, r0, r1 in parts)
             K = parts[0][0].shape[1]
             dev = parts[0][0].device
@@ -344,7 +376,7 @@ class Shadows:
         key = ("catv",) + tuple((id(p), r0, r1) for p, r0, r1 in parts)
         ent = self._d.get(key)
         ver = tuple((p._version, p.data_ptr()) for p, _, _ in parts) + (WEIGHTS_EPOCH,)
-        if (CAPTURING and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver:
+        if (CTX.capturing and (ent is None or ent[2] != STEP_ID)) or ent is None or ent[0] != ver:
             v = torch.cat([p.detach()[r0:r1] for p, r0, r1 in parts])
             if ent is not None and ent[1].shape == v.shape and ent[1].device == v.device:
                 ent[1].copy_(v)           # same storage: a captured graph keeps pointing at it
@@ -412,7 +444,7 @@ def padded_shadow(sh, p, kp):
     key = (id(p), "pad")
     ent = sh._d.get(key)
     ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
-    if CAPTURING or ent is None or ent[0] != ver or ent[1].device != p.device:
+    if CTX.capturing or ent is None or ent[0] != ver or ent[1].device != p.device:
         _require_gpu(p)
         _require_fp32_master(p)
         s_ = ent[1] if ent is not None and ent[1].device == p.device else \
@@ -608,7 +640,7 @@ def mx8_shadow(sh, p, rows=None):
     key = (id(p), "mx8", rows)
     ent = sh._d.get(key)
     ver = (p._version, p.data_ptr(), WEIGHTS_EPOCH)
-    if CAPTURING or ent is None or ent[0] != ver:
+    if CTX.capturing or ent is None or ent[0] != ver:
         _require_gpu(p)
         _require_fp32_master(p)
         src = p.detach()
@@ -922,7 +954,7 @@ class _DeferredReduce:
             dev = torch.empty((n, 8), dtype=torch.int64, device=self.device)
             _lib.call("hriemo_colreduce_batch", host.data_ptr(), n, _p(dev), nblocks, _stream())
             self.keep.append(dev)
-        if not CAPTURING and self.keep:     # a captured graph keeps using these buffers on every replay
+        if not CTX.capturing and self.keep:     # a captured graph keeps using these buffers on every replay
             cur = torch.cuda.current_stream(self.device)
             for t in self.keep:     # partials of the text branch were allocated on the side stream
                 t.record_stream(cur)
@@ -1003,7 +1035,7 @@ class _DeferredWgrad:
                 M, N = dy.shape
                 if not grouped:
                     gemm(1, 1, N, x.shape[1], M, dy, dy.stride(0), x, x.stride(0), out, out.stride(0), c_f32=True, accumulate=True)
-                if CAPTURING:
+                if CTX.capturing:
                     self.keep.extend((dy, x, out))      # a captured graph keeps reading these buffers on every replay
                 else:
                     dy.record_stream(cur); x.record_stream(cur); out.record_stream(cur)
@@ -1101,7 +1133,6 @@ def seq_bucket(cu, B, L, n_rows):
     return Seq(cu, idx, B + 1, L, L, n_rows, Breal=B)
 
 
-SEQ_OVERRIDE = None       # (Seq audio, Seq text) injected by dp.DataParallelStep for its bucketed packed graphs
 
 
 _SEQ_PLANS = {}
@@ -1116,7 +1147,7 @@ def seq_plan(mask, B, L):
     hit = _SEQ_PLANS.get(key)
     if hit is not None:
         return hit[0]
-    if CAPTURING:
+    if CTX.capturing:
         raise RuntimeError("varlen: the sequence lengths must be known before the step is captured (run one eager step first)")
     valid = ~mask.bool()
     lens = valid.sum(1)
@@ -1512,14 +1543,13 @@ def shared_proj():
     return SHARED_PROJ
 
 
-JOIN_SCOPE = 0          # > 0 inside a forward whose outputs ALL depend on both encoder branches (FusionWithEmotionDecoder)
 
 
 def grad_join(n=2, always=False):
     """a GradJoin where every consumer is certain to run its backward: the encoder's joins only inside the fusion model's forward
     (a stand-alone CrossModalBlock may be trained on one of its two outputs, and the unused branch's consumers never run), the
     decoder's (its layers are a chain) always"""
-    return GradJoin(n) if (GRAD_JOIN and torch.is_grad_enabled() and (always or JOIN_SCOPE > 0)) else None
+    return GradJoin(n) if (GRAD_JOIN and torch.is_grad_enabled() and (always or CTX.join_scope > 0)) else None
 
 
 class SharedGrad:
@@ -1580,12 +1610,12 @@ def _report_half(p, sink):
     hook = getattr(p, "_hriemo_grad_ready", None)
     if not sink.fused or hook is None:
         return
-    n = _half_reports.get(id(p), 0) + 1
+    n = CTX.half_reports.get(id(p), 0) + 1
     if n == 2:
-        _half_reports.pop(id(p), None)
+        CTX.half_reports.pop(id(p), None)
         hook(p)
     else:
-        _half_reports[id(p)] = n
+        CTX.half_reports[id(p)] = n
 
 
 class SharedProjFn(torch.autograd.Function):
@@ -1816,7 +1846,7 @@ class BetaGateFn(_GradModeAware, torch.autograd.Function):
             _lib.call("hriemo_ln_pool_fwd", _p(xa), _p(h_a32), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa),
                       B, La, L, d, _EPS, st)
             main.wait_stream(side)
-            if not CAPTURING:
+            if not CTX.capturing:
                 for t_ in (xt, h_t32, kpm_t, Tn, mean_t, rstd_t, pt):
                     share(t_, side)
         else:
@@ -1906,7 +1936,7 @@ class BetaGateFn(_GradModeAware, torch.autograd.Function):
                 ln_pool_bwd(0, dt, kpm_t, xt, h_t32, gt, mean_t, rstd_t, dxt, dgt, dbt, Lt, nbt)
             ln_pool_bwd(1, da, kpm_a, xa, h_a32, ga, mean_a, rstd_a, dxa, dga, dba, La, nba)
             main.wait_stream(side)
-            if not CAPTURING:
+            if not CTX.capturing:
                 for t_ in (dH2, w, dt, dxt, dgt, dbt):
                     share(t_, side)
         else:

@@ -154,9 +154,9 @@ class GradBuckets:
             from . import _ops
             streams = _ops.branch_streams(self.flat.device)
             cur = torch.cuda.current_stream(self.flat.device)
-            capturing = _ops.CAPTURING and _ops.CAPTURE_ORIGIN is not None
+            capturing = _ops.CTX.capturing and _ops.CTX.capture_origin is not None
             if capturing or self.launch_from == "main":
-                main = _ops.CAPTURE_ORIGIN if capturing else streams[0]
+                main = _ops.CTX.capture_origin if capturing else streams[0]
                 for st in streams:
                     if st != main:
                         main.wait_stream(st)
@@ -243,6 +243,18 @@ def shard_bounds(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def _in_step_context(fn):
+    """run a DataParallelStep method with the step's own _ops.StepContext in force"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        from . import _ops
+        with _ops.use_context(self.ctx):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class DataParallelStep:
     """fwd -> loss -> bwd -> gradient all-reduce for one shard; mirrors the order of operations of
     train_one_epoch (scripts/fusion/train_fusion_seq_level_decoder.py:310-334) minus the optimizer.
@@ -263,6 +275,8 @@ class DataParallelStep:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = GradBuckets(model.parameters(), bucket_bytes, group, overlap, comm_dtype, force_exchange, launch_from)
+        from . import _ops
+        self.ctx = _ops.StepContext()      # this step's capture flag / packed plan / join scope: not shared with another model's
         self._graph = None
         self._static = None
         self._static_loss = None
@@ -294,6 +308,7 @@ class DataParallelStep:
             loss.backward()
         return loss.detach()
 
+    @_in_step_context
     def step_accumulated(self, micro_batches):
         """Gradient accumulation (train_mosei_fusion_seq_level_decoder.py:387-396: loss / grad_accum, optimizer every grad_accum
         micro-steps) under data parallelism WITHOUT a gradient exchange per micro-step: the flat buffer is zeroed once, every
@@ -310,6 +325,7 @@ class DataParallelStep:
         self.buckets.finish()
         return total
 
+    @_in_step_context
     def capture(self, h_a, h_t, m_a, m_t, y, collectives=False, lengths=None):
         """Record one step on static copies of the batch tensors; later ``step()`` calls replay it.
 
@@ -431,7 +447,7 @@ class DataParallelStep:
         if side is None:
             side = DataParallelStep._capture_streams[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
-        _ops.SEQ_OVERRIDE = seqs
+        _ops.CTX.seq_override = seqs
         try:
             with torch.cuda.stream(side):                 # warm-up off the default stream, as graph capture wants
                 for _ in range(2):
@@ -451,8 +467,8 @@ class DataParallelStep:
             graph = torch.cuda.CUDAGraph()
             if seqs is not None and self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()       # the bucket graphs never run concurrently: one pool for all
-            _ops.CAPTURING = True
-            _ops.CAPTURE_ORIGIN = side        # every helper-stream fork of the step must start here (_ops.fork refuses nested forks)
+            _ops.CTX.capturing = True
+            _ops.CTX.capture_origin = side        # every helper-stream fork of the step must start here (_ops.fork refuses nested forks)
             _ops.begin_step()
             try:
                 # capture on the stream the warm-up ran on: its workspaces (keyed by stream) exist already, so nothing the
@@ -465,10 +481,10 @@ class DataParallelStep:
                     if collectives:
                         self.buckets.finish()         # waits on the captured collectives + the average: part of the graph
             finally:
-                _ops.CAPTURING = False
-                _ops.CAPTURE_ORIGIN = None
+                _ops.CTX.capturing = False
+                _ops.CTX.capture_origin = None
         finally:
-            _ops.SEQ_OVERRIDE = None
+            _ops.CTX.seq_override = None
         _ops.GRAPHS_ALIVE += 1            # from now on outgrown workspaces are retired, not freed (_ops.workspace)
         # buffers the captured kernels point into (column-sum partials, queued weight-gradient operands) live exactly as long as
         # this graph: they move from the process-wide lists to the graph's owner
@@ -495,6 +511,7 @@ class DataParallelStep:
         self._replay = bool(on) and self._graph is not None
         self.buckets.suspended = self._replay     # eager steps: the hooks drive the exchange; replays: it follows / is inside the graph
 
+    @_in_step_context
     def step(self, h_a, h_t, m_a, m_t, y, lengths=None):
         if self._graph is not None and getattr(self, "_replay", True):
             graph, loss = self._graph, self._static_loss

@@ -221,9 +221,9 @@ class CrossModalTransformer(nn.Module):
         _ops.FLUSH_SITES.add(self.layers[0]._site[1])        # layer-0 text self-attention: the last text-branch backward (_ops._DeferredWgrad)
         if _ops.varlen() and not need and mask_a is not None and mask_t is not None and _ops.precision() == "bf16":
             # the encoder on the valid rows only (prefix masks, as the collate builds them); anything else
-            # takes the padded path.  dp.DataParallelStep injects bucketed plans whose lengths are device data (_ops.SEQ_OVERRIDE).
-            if _ops.SEQ_OVERRIDE is not None:
-                sa, st = _ops.SEQ_OVERRIDE
+            # takes the padded path.  dp.DataParallelStep injects bucketed plans whose lengths are device data (_ops.CTX.seq_override).
+            if _ops.CTX.seq_override is not None:
+                sa, st = _ops.CTX.seq_override
             else:
                 sa = _ops.seq_plan(mask_a, a.shape[0], a.shape[1])
                 st = _ops.seq_plan(mask_t, t.shape[0], t.shape[1])

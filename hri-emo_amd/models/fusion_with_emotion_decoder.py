@@ -87,11 +87,11 @@ class FusionWithEmotionDecoder(nn.Module):
         # the decoder's serial chain behind the gate
         fused_early = self._build_fused_mask(mask_a, mask_t, h_t.size(1))
         ready = self._prefetch_shadows(a.device)
-        _ops.JOIN_SCOPE += 1          # logits, beta and z all depend on both branches: the encoder's gradient joins are safe
+        _ops.CTX.join_scope += 1          # logits, beta and z all depend on both branches: the encoder's gradient joins are safe
         try:
             a, a32, t, t32, encoder_attns = self.cross_modal._fwd_pair(a, a32, t, t32, mask_a, mask_t, need)
         finally:
-            _ops.JOIN_SCOPE -= 1
+            _ops.CTX.join_scope -= 1
         if ready is not None:
             torch.cuda.current_stream(a.device).wait_event(ready)
         h_fusion, beta = self.beta_gate._fwd_pair(a, a32, t, t32, mask_a, mask_t)

@@ -179,7 +179,7 @@ def test_nested_stream_fork_is_refused_during_capture():
 
     origin, side, helper = S(), S(), S()
     _ops.fork(helper, side)                       # outside a capture anything goes
-    _ops.CAPTURING, _ops.CAPTURE_ORIGIN = True, origin
+    _ops.CTX.capturing, _ops.CTX.capture_origin = True, origin
     try:
         _ops.fork(side, origin)                   # fork off the capture stream: fine
         _ops.fork(origin, side)                   # join back: fine
@@ -187,7 +187,7 @@ def test_nested_stream_fork_is_refused_during_capture():
             _ops.fork(helper, side)
         assert helper.waited == [side]            # only the eager call above reached the stream
     finally:
-        _ops.CAPTURING, _ops.CAPTURE_ORIGIN = False, None
+        _ops.CTX.capturing, _ops.CTX.capture_origin = False, None
 
 
 def test_hook_predicates_are_per_instance():
@@ -273,3 +273,31 @@ def test_bench_becomes_its_own_launcher_for_several_gpus(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_step_context_is_per_step_and_restored():
+    """_ops.StepContext: the capture flag / capture stream / packed plan / join scope / half-gradient bookkeeping of a step in
+    flight live in the context its DataParallelStep owns, installed by use_context and restored on the way out (re-entrant), so
+    two steps in one process do not see each other's state (VERDICT r3 #6)."""
+    import hri_emo_amd  # noqa: F401
+    from hri_emo_amd import _ops
+    base = _ops.CTX
+    a, b = _ops.StepContext(), _ops.StepContext()
+    assert a.half_reports is not b.half_reports and not a.capturing and a.seq_override is None and a.join_scope == 0
+    with _ops.use_context(a):
+        assert _ops.CTX is a
+        _ops.CTX.capturing = True
+        _ops.CTX.join_scope += 1
+        with _ops.use_context(b):
+            assert _ops.CTX is b and not _ops.CTX.capturing and _ops.CTX.join_scope == 0
+            _ops.CTX.half_reports[1] = 2
+        assert _ops.CTX is a and a.capturing and a.join_scope == 1 and not a.half_reports and b.half_reports == {1: 2}
+        try:
+            with _ops.use_context(b):
+                raise KeyError("x")
+        except KeyError:
+            pass
+        assert _ops.CTX is a                       # restored on an exception too
+    assert _ops.CTX is base and not base.capturing
+    from hri_emo_amd import dp
+    assert dp.DataParallelStep.step.__wrapped__ is not None and dp.DataParallelStep.capture.__wrapped__ is not None
