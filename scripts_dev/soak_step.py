@@ -25,6 +25,9 @@ if ragged:
     la, lt = torch.randint(200, 401, (B,), generator=g_), torch.randint(64, 129, (B,), generator=g_)
     batch = (batch[0], batch[1], (torch.arange(400)[None] >= la[:, None]).to(dev), (torch.arange(128)[None] >= lt[:, None]).to(dev), batch[4])
 names = {id(p): nm for nm, p in model.named_parameters()}
+if "GEMM_FLAGS" in os.environ:                             # e.g. 1 = the loader / consumer GEMMs draw their tiles from the work queue
+    from hri_emo_amd import _lib
+    _lib.lib().hriemo_gemm_debug_flags(int(os.environ["GEMM_FLAGS"]))
 if os.environ.get("VARLEN", "0") == "1":                   # the packed (varlen) bucket graph: surplus rows must never leak into a sum
     H.set_varlen(True)
 dp.step(*batch)
@@ -60,4 +63,4 @@ valid = float((~batch[2]).float().mean() + (~batch[3]).float().mean()) / 2
 print(f"STEP SOAK {'CLEAN' if bad_replays == 0 else 'DIRTY'}: {bad_replays} of {n - 1} replays differ ({bad_elems} words) -- "
       f"{(n - 1) * ref.numel():.3g} gradient words compared")
 print(f"STEP SOAK configuration: argv {sys.argv[1:]}, B {B}, ragged {ragged} (valid fraction {valid:.3f}), {packed}, "
-      f"two streams {_ops.side_stream(dev) is not None}, gemm {_ops.gemm_mode()}, precision {_ops.precision()}")
+      f"two streams {_ops.side_stream(dev) is not None}, gemm {_ops.gemm_mode()}, precision {_ops.precision()}, GEMM_FLAGS {os.environ.get('GEMM_FLAGS', 'default (9)')}")
