@@ -41,10 +41,13 @@ class FusionWithEmotionDecoder(nn.Module):
         _ops.fork(side, main)                       # the masters may have just been updated on the caller's stream
         with torch.cuda.stream(side):
             g = self.beta_gate
-            g._sh.prefetch((g.mlp[0].weight, g.mlp[2].weight))
+            pairs = [(g._sh, g.mlp[0].weight), (g._sh, g.mlp[2].weight)]
             for layer in self.emotion_decoder.layers:
-                layer._sh.prefetch((layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.cross_attn.in_proj_weight,
-                                    layer.cross_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight))
+                pairs += [(layer._sh, w) for w in (layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight,
+                                                   layer.cross_attn.in_proj_weight, layer.cross_attn.out_proj.weight,
+                                                   layer.linear1.weight, layer.linear2.weight)]
+            _ops.prefetch_batch(pairs)          # one launch for the fourteen matrices (the step time is the same as with fourteen:
+            #                                     7.45 vs 7.45 ms -- the graph runtime starts the branches late either way)
             ev = torch.cuda.Event()
             ev.record(side)
         return ev
