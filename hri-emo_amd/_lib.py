@@ -97,6 +97,7 @@ _SIGS = {
     "hriemo_fuse_bwd_dw": ("ppppiiip", "i"),
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),
     "hriemo_gate_input_bwd": ("ppppppiip", "i"),
+    "hriemo_ln_pool_bwd_chunks": ("i", "i"),
     "hriemo_ln_pool_bwd_workspace_bytes": ("iii", "l"),
     "hriemo_ln_pool_bwd": ("pipipppppppppp" + "iiiipp", "i"),
     "hriemo_prof_enable": ("i", "i"),

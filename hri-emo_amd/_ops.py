@@ -1954,7 +1954,7 @@ class BetaGateFn(_GradModeAware, torch.autograd.Function):
                 wsx = torch.empty(nbytes // 4 + 16, **f32)
                 _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), is_a, _p(dpool), _p(kpm), _p(x), _p(x32), _p(gamma), _p(mean),
                           _p(rstd), _p(dx), None, None, 1, B, Lx, d, _p(wsx), _stream())
-                _deferred.add(wsx, 2 * d, B * ((Lx + 31) // 32), d, 2, [dgam, dbet], True)
+                _deferred.add(wsx, 2 * d, B * L_.hriemo_ln_pool_bwd_chunks(Lx), d, 2, [dgam, dbet], True)
             else:
                 wsx = workspace(nbytes, dev, slot=1)
                 _lib.call("hriemo_ln_pool_bwd", _p(dH2), L, _p(w), is_a, _p(dpool), _p(kpm), _p(x), _p(x32), _p(gamma), _p(mean),

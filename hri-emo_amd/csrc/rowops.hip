@@ -863,6 +863,9 @@ __global__ __launch_bounds__(256) void gate_input_bwd_kernel(const bf16_t* __res
   }
 }
 
+// rows of one sample that one block of ln_pool_bwd walks (4 waves, POOL_BWD_ROWS / 4 rows each); its partial sums are per block
+constexpr int POOL_BWD_ROWS = 16;
+
 // backward of LayerNorm+pool+fuse-branch for one modality:
 //   dYn[l] = (l < Lf ? coef * dH[b,l] : 0) + (valid_l ? dpool[b] : 0),  coef = is_a ? w : 1-w ;  dX = LN'(dYn)
 template <int NCH>
@@ -905,10 +908,38 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
       }
     }
   }
-  for (int l = chunk * 32 + wave; l < min(L, chunk * 32 + 32); l += 4) {
+  // a wave walks its POOL_BWD_ROWS / 4 rows one after the other and every row is one trip to HBM: the next row's operands are
+  // requested before this row's reductions (one row in flight per wave and 178 registers, i.e. two waves per SIMD, held the
+  // kernel at 2.5 TB/s; 32-row chunks also left a second, one-third-full round of blocks on the 256 CUs)
+  const int lbeg = chunk * POOL_BWD_ROWS + wave, lend = min(L, chunk * POOL_BWD_ROWS + POOL_BWD_ROWS);
+  const bool has_dh = dH != nullptr;
+  float nxx[NCH][8];
+  bf16x8 nxh[NCH];
+  auto load_row = [&](int l) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunk) {
+        load_resid(X, X32, ((long)b * L + l) * d + ch * 8, nxx[c]);
+        if (has_dh && l < Lf) nxh[c] = *(const bf16x8*)(dH + ((long)b * Lf + l) * d + ch * 8);
+      }
+    }
+  };
+  constexpr bool PF = NCH <= 2;   // wider rows (d > 1024) would spill with a second row in registers
+  if (PF) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) nxx[c][j] = 0.f;
+      nxh[c] = bf16x8{};
+    }
+  }
+  if (PF && lbeg < lend) load_row(lbeg);
+  for (int l = lbeg; l < lend; l += 4) {
     const long row = (long)b * L + l;
     const float mu = mean_i[row], rstd = rstd_i[row];
     const bool valid = mask == nullptr || mask[row] == 0;
+    const bool grad_row = has_dh && l < Lf;
     float xh[NCH][8], dyg[NCH][8];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -916,21 +947,31 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
       const int ch = lane + 64 * c;
       if (ch < nchunk) {
         float xf[8], gh[8];
-        load_resid(X, X32, row * d + ch * 8, xf);
-        if (dH != nullptr && l < Lf) bf8_to_f32(*(const bf16x8*)(dH + ((long)b * Lf + l) * d + ch * 8), gh);
+        if (PF) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xf[j] = nxx[c][j];
+          bf8_to_f32(nxh[c], gh);
+        } else {
+          load_resid(X, X32, row * d + ch * 8, xf);
+          if (grad_row) bf8_to_f32(*(const bf16x8*)(dH + ((long)b * Lf + l) * d + ch * 8), gh);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float dy = valid ? dp8[c][j] : 0.f;
-          if (dH != nullptr && l < Lf) dy += wv8[c][j] * gh[j];
+          if (grad_row) dy += wv8[c][j] * gh[j];
           xh[c][j] = (xf[j] - mu) * rstd;
           dyg[c][j] = dy * gm8[c][j];
           c1 += dyg[c][j];
+          // keeps the SLP vectoriser from pairing steps of this serial sum: with the prefetch in the loop it chose the packed add
+          // whose low half reads the high dword of src1, the form `make check-isa` rejects (Makefile, ATTN_FLAGS)
+          if (PF) asm volatile("" : "+v"(c1));
           c2 += dyg[c][j] * xh[c][j];
           ag[c][j] += dy * xh[c][j];
           ab[c][j] += dy;
         }
       }
     }
+    if (PF && l + 4 < lend) load_row(l + 4);
     c1 = wave_sum(c1) * invd;
     c2 = wave_sum(c2) * invd;
 #pragma unroll
@@ -1626,21 +1667,22 @@ extern "C" int hriemo_gate_input_bwd(const void* dgin, const float* a_pool, cons
   return 0;
 }
 
-extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return ((long)B * ((L + 31) / 32) * 2 * d + 64L * 2 * d) * 4; }
+extern "C" int hriemo_ln_pool_bwd_chunks(int L) { return (L + POOL_BWD_ROWS - 1) / POOL_BWD_ROWS; }
+extern "C" long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d) { return ((long)B * hriemo_ln_pool_bwd_chunks(L) * 2 * d + 64L * 2 * d) * 4; }
 
 extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                                   const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
                                   float* dgamma, float* dbeta, int accumulate, int B, int L, int d, float* workspace, hipStream_t st) {
   if (check_rows(B * L, d)) return 1;
   HRIEMO_CHECK(workspace != nullptr && Lf <= L && (dgamma == nullptr) == (dbeta == nullptr), "ln_pool_bwd: bad arguments");
-  const int nc = (L + 31) / 32;
+  const int nc = hriemo_ln_pool_bwd_chunks(L);
   hriemo_prof_begin(HP_ROWOPS, st);
 #define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), 2 * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");
   hriemo_prof_end(HP_ROWOPS, st, (2.0 * B * L + (double)B * Lf) * d * 2);
-  if (dgamma == nullptr) return 0;          // partial sums stay in `workspace` ([B * ceil(L/32)][2d]) for the launch-boundary reduce
+  if (dgamma == nullptr) return 0;          // partial sums stay in `workspace` ([B * hriemo_ln_pool_bwd_chunks(L)][2d]) for the launch-boundary reduce
   float* scratch = workspace + (long)B * nc * 2 * d;
   ReduceOut ro; ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = nullptr;
   launch_colreduce(workspace, (long)2 * d, B * nc, ro, d, 2, accumulate, scratch, st);

@@ -303,6 +303,8 @@ int hriemo_colsum_partial_rows(int M, int N);
 int hriemo_colreduce_batch(const void* jobs_host, int njobs, void* jobs_dev, int nblocks, hriemo_stream_t stream);
 /* tuning hook: `blocks` CUs made unavailable for ~`micros` us (stands in for a collective running beside the step) */
 int hriemo_debug_hog(int blocks, int micros, float* sink, hriemo_stream_t stream);
+/* row chunks per sample of hriemo_ln_pool_bwd: its partial sums are [B * chunks][2 d] floats at the head of `workspace` */
+int hriemo_ln_pool_bwd_chunks(int L);
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);
 int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is_a, const float* dpool, const unsigned char* mask,
                        const void* X, const float* X32, const float* gamma, const float* mean, const float* rstd, void* dX,
