@@ -439,7 +439,9 @@ class GradSink:
                     continue
                 hook = getattr(p, "_hriemo_grad_ready", None)
                 if hook is not None:
-                    if (p.dim() < 2 or any(p is q for q in after_flush)) and DEFER_REDUCE and _in_backward():
+                    if p.dim() < 2 and _small_dw.touches(p.grad):
+                        _small_dw.add_hook(hook, p)       # its column sum is still queued (decoder / gate sized bias gradient)
+                    elif (p.dim() < 2 or any(p is q for q in after_flush)) and DEFER_REDUCE and _in_backward():
                         _deferred.add_hook(hook, p)       # bias / LayerNorm gradients are final only after the flush
                     elif p.dim() >= 2 and _small_dw.touches(p.grad):
                         _small_dw.add_hook(hook, p)       # its weight-gradient GEMM is still queued
@@ -777,7 +779,10 @@ def proj_add_ln_fwd(a, w16, bias, x, x32, gamma, beta, p, seed, site, row_off, w
 def colsum(x, out, accumulate=False):
     M, N = x.shape
     L_ = _lib.lib()
-    if accumulate and DEFER_REDUCE and _in_backward():
+    if accumulate and M <= SMALL_DW_ROWS and not _small_dw.flushing and _small_dw.enabled():
+        _small_dw.add(x, None, out)        # decoder / gate sized bias gradient: off the serial chain, like the weight gradients
+        return
+    if accumulate and DEFER_REDUCE and _in_backward() and not _small_dw.in_final:
         rows = L_.hriemo_colsum_partial_rows(M, N)
         part = torch.empty(rows * N, dtype=torch.float32, device=x.device)
         _lib.call("hriemo_colsum_bf16", _p(x), x.stride(0), M, N, None, 0, _p(part), _stream())
@@ -1007,6 +1012,7 @@ _deferred = _DeferredReduce()
 # self-attention, on the side stream, while the audio branch still has ~0.5 ms of its own backward to run), or from an
 # autograd-engine final callback if no such point comes.  Measured at cfg 2: 8.87 -> 8.7 ms per step (skipping them altogether:
 # 8.65).  Off while gradient-ready hooks drive an overlapped exchange (the decoder's bucket would leave last instead of first);
+# round 4: the same sites' bias-gradient column sums (five 5-7 us launches on the chain) are queued with them.
 GATE_TWO_STREAMS = True    # the gate's text-side LayerNorm + pooling on the side stream
 DEFER_SMALL_DW = True
 GROUP_SMALL_DW = True      # the queued weight gradients leave as one grouped GEMM launch
@@ -1033,6 +1039,7 @@ def grad_hooks_active():
 class _DeferredWgrad:
     def __init__(self):
         self.jobs, self.hooks, self.keep, self.scheduled = [], [], [], False
+        self.flushing = self.in_final = False
 
     def enabled(self):
         return DEFER_SMALL_DW and _in_backward() and not grad_hooks_active()
@@ -1054,7 +1061,21 @@ class _DeferredWgrad:
         return any(a <= j[2].data_ptr() < b for j in self.jobs)
 
     def flush(self):
-        jobs, self.jobs = self.jobs, []
+        alljobs, self.jobs = self.jobs, []
+        sums = [j for j in alljobs if j[1] is None]          # queued column sums (x is None): (dy, None, out)
+        jobs = [j for j in alljobs if j[1] is not None]
+        if sums:
+            cur = torch.cuda.current_stream(sums[0][0].device)
+            self.flushing = True
+            try:
+                for dy, _, out in sums:
+                    colsum(dy, out, True)
+                    if CTX.capturing:
+                        self.keep.extend((dy, out))
+                    else:
+                        dy.record_stream(cur); out.record_stream(cur)
+            finally:
+                self.flushing = False
         if jobs:
             cur = torch.cuda.current_stream(jobs[0][0].device)
             grouped = GROUP_SMALL_DW and all(dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 for dy, x, _ in jobs)
@@ -1074,11 +1095,18 @@ class _DeferredWgrad:
                     dy.record_stream(cur); x.record_stream(cur); out.record_stream(cur)
         hooks, self.hooks = self.hooks, []
         for hook, p in hooks:
-            hook(p)
+            if p.dim() < 2 and DEFER_REDUCE and not self.in_final and _in_backward():
+                _deferred.add_hook(hook, p)          # the column sum just issued is finished by the launch-boundary reduce
+            else:
+                hook(p)
 
     def final(self):
         self.scheduled = False
-        self.flush()
+        self.in_final = True             # engine final callback: column sums finish in their own call, nothing is queued any more
+        try:
+            self.flush()
+        finally:
+            self.in_final = False
 
 
 _small_dw = _DeferredWgrad()
