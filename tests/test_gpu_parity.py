@@ -1366,3 +1366,40 @@ def test_fused_linear_layernorm_sites_give_the_same_training_step(H, monkeypatch
         assert e <= (0.15 if n in gate else 2 * GRAD_FLOOR), ("worst five:", rows[:5])
     assert _rel(ga1, ga0) <= GRAD_FLOOR and _rel(gt1, gt0) <= GRAD_FLOOR
     print(f"fused vs separate (varlen {varlen}): worst five {[(round(e, 4), n) for e, n in rows[:5]]}")
+
+
+@pytest.mark.gpu
+def test_queued_small_gradients_equal_the_unqueued_ones(H, monkeypatch):
+    """hri_emo_amd._ops._DeferredWgrad: the decoder's and the gate's weight gradients AND (round 4) their bias-gradient column sums
+    leave the serial chain and are issued at the end of the text branch's backward.  The column sums run the same kernels on the
+    same partial sums and end in the same launch-boundary reduce: every vector gradient must hold the same bits with the queue on
+    and off.  The queued weight gradients leave through the grouped GEMM launch (another tile, another summation order): equal
+    to fp32 rounding.  Dropout is active: the decoder FFN's mid dropout sits between the two queued column sums."""
+    from hri_emo_amd import _ops
+    from hri_emo_amd.dp import DataParallelStep
+    from hri_emo_amd.train import fusion_step_loss
+    kw = dict(d_model=256, num_emotions=5, n_heads=8, dropout=0.1)
+    b = tuple(cu(t) for t in _rand_batch(4, 90, 40, 256, 77))
+    y = (torch.rand(4, 5, generator=torch.Generator().manual_seed(3)) < 0.3).float().cuda()
+    torch.manual_seed(11)
+    m = H.FusionWithEmotionDecoder(**kw).cuda().train()       # ONE model: dropout sites are numbered per module instance
+    dp = DataParallelStep(m, fusion_step_loss, overlap=False)
+    grads = {}
+    for on in (True, False, True):
+        monkeypatch.setattr(_ops, "DEFER_SMALL_DW", on)
+        torch.manual_seed(12)                                   # the same per-call dropout seeds ...
+        _ops.seed_word(torch.device("cuda", 0)).zero_()         # ... on top of the same device seed word
+        dp.step(*b, y)
+        torch.cuda.synchronize()
+        g = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        assert all(torch.isfinite(t).all() for t in g.values())
+        if on in grads:                                         # the step itself is reproducible from its seeds
+            assert all(torch.equal(g[n], grads[on][n]) for n in g)
+        grads[on] = g
+    assert grads[True]["beta_gate.mlp.0.bias"].abs().max() > 0 and grads[True]["emotion_decoder.layers.0.linear1.bias"].abs().max() > 0
+    for n, g in grads[True].items():
+        r = grads[False][n]
+        if g.dim() < 2:
+            assert torch.equal(g, r), (n, (g - r).abs().max().item())
+        else:
+            assert (g - r).abs().max() <= 2e-5 * max(1e-3, r.abs().max().item()), (n, (g - r).abs().max().item(), r.abs().max().item())
