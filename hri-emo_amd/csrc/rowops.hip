@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                           bf16_t* __restrict__ dX, float* __restrict__ partials, int L, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = (float*)smem_raw;   // [2][d]
+  float* red = (float*)smem_raw;   // [2][d] column-sum scratch (+ [3][d] constants for d <= 1024)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, chunk = blockIdx.x, nchunk = d >> 3;
   const float invd = 1.f / (float)d;
@@ -884,26 +884,39 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ag[c][j] = 0.f; ab[c][j] = 0.f; }
-  // per-column constants of this sample (pooled gradient, gate weight, LN gain): registers, loaded once per block
-  // instead of once per row (as scalar loads inside the row loop they made this kernel 3x slower than its traffic)
-  float dp8[NCH][8], wv8[NCH][8], gm8[NCH][8];
+  // per-column constants of this sample (pooled gradient, gate weight, LN gain), loaded once per block instead of once per row
+  // (as scalar loads inside the row loop they made this kernel 3x slower than its traffic): in registers for wide rows; for
+  // d <= 1024 in LDS behind the column-sum scratch (48 registers less: three waves per SIMD instead of two beside the prefetch)
+  constexpr bool CLDS = NCH <= 2;
+  float* cst = red + 2 * d;   // [3][d], CLDS only
+  float dp8[CLDS ? 1 : NCH][8], wv8[CLDS ? 1 : NCH][8], gm8[CLDS ? 1 : NCH][8];
+  if (CLDS) {
+    for (int t = threadIdx.x; t < d; t += 256) {
+      const float wt = dH != nullptr ? w[(long)b * d + t] : 0.f;
+      cst[t] = dpool[(long)b * d + t];
+      cst[d + t] = is_a ? wt : 1.f - wt;
+      cst[2 * d + t] = gamma[t];
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int ch = lane + 64 * c;
+    for (int c = 0; c < (CLDS ? 1 : NCH); ++c) {
+      const int ch = lane + 64 * c;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { dp8[c][j] = 0.f; wv8[c][j] = 0.f; gm8[c][j] = 0.f; }
-    if (ch < nchunk) {
+      for (int j = 0; j < 8; ++j) { dp8[c][j] = 0.f; wv8[c][j] = 0.f; gm8[c][j] = 0.f; }
+      if (ch < nchunk) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 a = *(const f32x4*)(dpool + (long)b * d + ch * 8 + h * 4);
-        const f32x4 g4 = *(const f32x4*)(gamma + ch * 8 + h * 4);
-        f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
-        if (dH != nullptr) w4 = *(const f32x4*)(w + (long)b * d + ch * 8 + h * 4);
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 a = *(const f32x4*)(dpool + (long)b * d + ch * 8 + h * 4);
+          const f32x4 g4 = *(const f32x4*)(gamma + ch * 8 + h * 4);
+          f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+          if (dH != nullptr) w4 = *(const f32x4*)(w + (long)b * d + ch * 8 + h * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dp8[c][h * 4 + e] = a[e];
-          gm8[c][h * 4 + e] = g4[e];
-          wv8[c][h * 4 + e] = is_a ? w4[e] : 1.f - w4[e];
+          for (int e = 0; e < 4; ++e) {
+            dp8[c][h * 4 + e] = a[e];
+            gm8[c][h * 4 + e] = g4[e];
+            wv8[c][h * 4 + e] = is_a ? w4[e] : 1.f - w4[e];
+          }
         }
       }
     }
@@ -946,7 +959,20 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
       if (ch < nchunk) {
-        float xf[8], gh[8];
+        float xf[8], gh[8], dpc[8], wvc[8], gmc[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 a, wq, g4;
+          if (CLDS) {
+            a = *(const f32x4*)(cst + ch * 8 + h * 4); wq = *(const f32x4*)(cst + d + ch * 8 + h * 4); g4 = *(const f32x4*)(cst + 2 * d + ch * 8 + h * 4);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dpc[h * 4 + e] = CLDS ? a[e] : dp8[CLDS ? 0 : c][h * 4 + e];
+            wvc[h * 4 + e] = CLDS ? wq[e] : wv8[CLDS ? 0 : c][h * 4 + e];
+            gmc[h * 4 + e] = CLDS ? g4[e] : gm8[CLDS ? 0 : c][h * 4 + e];
+          }
+        }
         if (PF) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) xf[j] = nxx[c][j];
@@ -957,10 +983,10 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float dy = valid ? dp8[c][j] : 0.f;
-          if (grad_row) dy += wv8[c][j] * gh[j];
+          float dy = valid ? dpc[j] : 0.f;
+          if (grad_row) dy += wvc[j] * gh[j];
           xh[c][j] = (xf[j] - mu) * rstd;
-          dyg[c][j] = dy * gm8[c][j];
+          dyg[c][j] = dy * gmc[j];
           c1 += dyg[c][j];
           // keeps the SLP vectoriser from pairing steps of this serial sum: with the prefetch in the loop it chose the packed add
           // whose low half reads the high dword of src1, the form `make check-isa` rejects (Makefile, ATTN_FLAGS)
@@ -1677,7 +1703,7 @@ extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is
   HRIEMO_CHECK(workspace != nullptr && Lf <= L && (dgamma == nullptr) == (dbeta == nullptr), "ln_pool_bwd: bad arguments");
   const int nc = hriemo_ln_pool_bwd_chunks(L);
   hriemo_prof_begin(HP_ROWOPS, st);
-#define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), 2 * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
+#define CALL(N) hipLaunchKernelGGL((ln_pool_bwd_kernel<N>), dim3(nc, B), dim3(256), ((N) <= 2 ? 5 : 2) * d * 4, st, (const bf16_t*)dH, Lf, w, is_a, dpool, mask, (const bf16_t*)X, X32, gamma, mean, rstd, (bf16_t*)dX, workspace, L, d)
   DISPATCH_NCH(d, CALL)
 #undef CALL
   HRIEMO_LAUNCH_CHECK("ln_pool_bwd_kernel");
