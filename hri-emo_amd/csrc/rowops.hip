@@ -628,16 +628,19 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* __restric
   if (lane == 0) out[row] = s + (b != nullptr ? b[0] : 0.f);
 }
 // dZ[r,:] = dl[r]*w ; dw[e] = sum_r dl[r] z[r,e] ; db = sum_r dl[r]   (M is small: B*N_e)
-__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ Z32, const float* __restrict__ w,
+// 32 columns per block and ROWDOT_GROUPS row groups of 32 lanes: the kernel sits on the step's serial chain right behind the loss
+// and its duration is the length of a group's row loop (8 groups x 48 rows at cfg 2: 17 us; 32 groups x 12 rows: see HISTORY)
+constexpr int ROWDOT_GROUPS = 32;
+__global__ __launch_bounds__(ROWDOT_GROUPS * 32) void rowdot_bwd_kernel(const float* __restrict__ dl, const bf16_t* __restrict__ Z, const float* __restrict__ Z32, const float* __restrict__ w,
                                                          bf16_t* __restrict__ dZ, float* __restrict__ dw, float* __restrict__ db, int M, int d,
                                                          int accumulate) {
-  __shared__ float red[8][33];
+  __shared__ float red[ROWDOT_GROUPS][33];
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;
   float acc = 0.f, sb = 0.f;
   if (col < d) {
     const float wc = w[col];
-    for (int r = g; r < M; r += 8) {
+    for (int r = g; r < M; r += ROWDOT_GROUPS) {
       const float gr = dl[r];
       acc += gr * (Z32 != nullptr ? Z32[(long)r * d + col] : (float)Z[(long)r * d + col]);
       dZ[(long)r * d + col] = (bf16_t)(gr * wc);
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
   if (g == 0 && col < d) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][c];
+    for (int k = 0; k < ROWDOT_GROUPS; ++k) t += red[k][c];
     dw[col] = accumulate ? dw[col] + t : t;
   }
   __syncthreads();
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.f;
-      for (int k = 0; k < 8; ++k) t += red[k][0];
+      for (int k = 0; k < ROWDOT_GROUPS; ++k) t += red[k][0];
       db[0] = accumulate ? db[0] + t : t;
     }
   }
@@ -745,21 +748,38 @@ __global__ __launch_bounds__(256) void gate_input_kernel(const float* __restrict
                                                          const uint8_t* __restrict__ mask_a, const uint8_t* __restrict__ mask_t, int La, int Lt,
                                                          int d, bf16_t* __restrict__ gin, float* __restrict__ a_pool, float* __restrict__ t_pool,
                                                          float* __restrict__ cnt) {
-  __shared__ float sc[2];
+  // on the step's serial chain: every load of a phase is requested before the first one is used.  The valid counts are small
+  // integers (any summation order gives the same float); the partial sums are added in chunk order, as before.
+  __shared__ float sc[2], wc[4][2];
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < 64) {
-    float ca = 0.f, ct = 0.f;
-    for (int l = tid; l < La; l += 64) ca += (mask_a == nullptr || mask_a[(long)b * La + l] == 0) ? 1.f : 0.f;
-    for (int l = tid; l < Lt; l += 64) ct += (mask_t == nullptr || mask_t[(long)b * Lt + l] == 0) ? 1.f : 0.f;
-    ca = wave_sum(ca); ct = wave_sum(ct);
-    if (tid == 0) { sc[0] = fmaxf(ca, 1.f); sc[1] = fmaxf(ct, 1.f); cnt[b * 2] = sc[0]; cnt[b * 2 + 1] = sc[1]; }
+  float ca = 0.f, ct = 0.f;
+  for (int l = tid; l < La; l += 256) ca += (mask_a == nullptr || mask_a[(long)b * La + l] == 0) ? 1.f : 0.f;
+  for (int l = tid; l < Lt; l += 256) ct += (mask_t == nullptr || mask_t[(long)b * Lt + l] == 0) ? 1.f : 0.f;
+  ca = wave_sum(ca); ct = wave_sum(ct);
+  if ((tid & 63) == 0) { wc[tid >> 6][0] = ca; wc[tid >> 6][1] = ct; }
+  __syncthreads();
+  if (tid == 0) {
+    sc[0] = fmaxf(wc[0][0] + wc[1][0] + wc[2][0] + wc[3][0], 1.f); sc[1] = fmaxf(wc[0][1] + wc[1][1] + wc[2][1] + wc[3][1], 1.f);
+    cnt[b * 2] = sc[0]; cnt[b * 2 + 1] = sc[1];
   }
   __syncthreads();
   const float ia = 1.f / sc[0], it = 1.f / sc[1];
   for (int c = tid; c < d; c += 256) {
     float a = 0.f, t = 0.f;
-    for (int k = 0; k < nca; ++k) a += pa[((long)b * nca + k) * d + c];
-    for (int k = 0; k < nct; ++k) t += pt[((long)b * nct + k) * d + c];
+    for (int k0 = 0; k0 < nca; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = k0 + k < nca ? pa[((long)b * nca + k0 + k) * d + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k0 + k < nca) a += v[k];
+    }
+    for (int k0 = 0; k0 < nct; k0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = k0 + k < nct ? pt[((long)b * nct + k0 + k) * d + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k0 + k < nct) t += v[k];
+    }
     a *= ia; t *= it;
     a_pool[(long)b * d + c] = a; t_pool[(long)b * d + c] = t;
     bf16_t* g = gin + (long)b * 4 * d;
@@ -1427,7 +1447,7 @@ extern "C" int hriemo_rowdot_fwd(const void* Z, const float* Z32, const float* w
 extern "C" int hriemo_rowdot_bwd(const float* dl, const void* Z, const float* Z32, const float* w, void* dZ, float* dw, float* db,
                                  int accumulate, int M, int d, hipStream_t st) {
   if (check_rows(M, d)) return 1;
-  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(256), 0, st, dl, (const bf16_t*)Z, Z32, w, (bf16_t*)dZ, dw, db, M, d, accumulate);
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((d + 31) / 32), dim3(ROWDOT_GROUPS * 32), 0, st, dl, (const bf16_t*)Z, Z32, w, (bf16_t*)dZ, dw, db, M, d, accumulate);
   HRIEMO_LAUNCH_CHECK("rowdot_bwd_kernel");
   return 0;
 }
