@@ -861,8 +861,14 @@ __global__ __launch_bounds__(256) void gate_dpre_kernel(const float* __restrict_
   const float db = dbeta != nullptr ? dbeta[b] / (float)d : 0.f;
   for (int c = threadIdx.x; c < d; c += 256) {
     float s = db;
-    for (int k = 0; k < np; ++k) s += partials[((long)b * np + k) * d + c];
     const float wv = w[(long)b * d + c];
+    for (int k0 = 0; k0 < np; k0 += 8) {        // loads of a chunk requested together, added in chunk order
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = k0 + k < np ? partials[((long)b * np + k0 + k) * d + c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (k0 + k < np) s += v[k];
+    }
     dpre[(long)b * d + c] = (bf16_t)(s * wv * (1.f - wv));
   }
 }
