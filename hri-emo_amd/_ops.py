@@ -439,8 +439,8 @@ class GradSink:
                     continue
                 hook = getattr(p, "_hriemo_grad_ready", None)
                 if hook is not None:
-                    if p.dim() < 2 and _small_dw.touches(p.grad):
-                        _small_dw.add_hook(hook, p)       # its column sum is still queued (decoder / gate sized bias gradient)
+                    if (p.dim() < 2 or any(p is q for q in after_flush)) and _small_dw.touches(p.grad):
+                        _small_dw.add_hook(hook, p, True)     # its column sum is still queued (decoder / gate sized bias gradient)
                     elif (p.dim() < 2 or any(p is q for q in after_flush)) and DEFER_REDUCE and _in_backward():
                         _deferred.add_hook(hook, p)       # bias / LayerNorm gradients are final only after the flush
                     elif p.dim() >= 2 and _small_dw.touches(p.grad):
@@ -1050,8 +1050,8 @@ class _DeferredWgrad:
             torch.autograd.Variable._execution_engine.queue_callback(self.final)
             self.scheduled = True
 
-    def add_hook(self, hook, p):
-        self.hooks.append((hook, p))
+    def add_hook(self, hook, p, column_sum=False):
+        self.hooks.append((hook, p, column_sum))
 
     def touches(self, g):
         if not self.jobs or g is None:
@@ -1094,8 +1094,8 @@ class _DeferredWgrad:
                 else:
                     dy.record_stream(cur); x.record_stream(cur); out.record_stream(cur)
         hooks, self.hooks = self.hooks, []
-        for hook, p in hooks:
-            if p.dim() < 2 and DEFER_REDUCE and not self.in_final and _in_backward():
+        for hook, p, column_sum in hooks:
+            if column_sum and DEFER_REDUCE and not self.in_final and _in_backward():
                 _deferred.add_hook(hook, p)          # the column sum just issued is finished by the launch-boundary reduce
             else:
                 hook(p)
