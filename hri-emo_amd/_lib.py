@@ -98,6 +98,9 @@ _SIGS = {
     "hriemo_gate_dpre": ("pippp" + "iip", "i"),
     "hriemo_gate_input_bwd": ("ppppppiip", "i"),
     "hriemo_ln_pool_bwd_chunks": ("i", "i"),
+    "hriemo_ln_pool_pair_supported": ("i", "i"),
+    "hriemo_ln_pool_fwd_pair": ("pppppppppi" * 2 + "iiifp", "i"),
+    "hriemo_ln_pool_bwd_pair": ("pip" + "ppppppppppip" * 2 + "iiip", "i"),
     "hriemo_ln_pool_bwd_workspace_bytes": ("iii", "l"),
     "hriemo_ln_pool_bwd": ("pipipppppppppp" + "iiiipp", "i"),
     "hriemo_prof_enable": ("i", "i"),

@@ -1014,6 +1014,7 @@ _deferred = _DeferredReduce()
 # 8.65).  Off while gradient-ready hooks drive an overlapped exchange (the decoder's bucket would leave last instead of first);
 # round 4: the same sites' bias-gradient column sums (five 5-7 us launches on the chain) are queued with them.
 GATE_TWO_STREAMS = True    # the gate's text-side LayerNorm + pooling on the side stream
+GATE_PAIR = True           # ... superseded for d <= 1024: both modalities' LayerNorm + pooling (forward and backward) from ONE launch
 DEFER_SMALL_DW = True
 GROUP_SMALL_DW = True      # the queued weight gradients leave as one grouped GEMM launch
 SMALL_DW_ROWS = 1024
@@ -1899,7 +1900,11 @@ class BetaGateFn(_GradModeAware, torch.autograd.Function):
         # the two modalities' LayerNorm + pooling are independent: the (small) text one runs on the side stream beside the audio one
         main = torch.cuda.current_stream(dev)
         side = side_stream(dev) if GATE_TWO_STREAMS else None
-        if side is not None and side != main:
+        if GATE_PAIR and L_.hriemo_ln_pool_pair_supported(d):
+            # both modalities from one launch: no fork / join around the step (two graph edges and 10-27 us of idle device each)
+            _lib.call("hriemo_ln_pool_fwd_pair", _p(xa), _p(h_a32), _p(kpm_a), _p(ga), _p(ba), _p(An), _p(mean_a), _p(rstd_a), _p(pa), La,
+                      _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt), Lt, B, L, d, _EPS, st)
+        elif side is not None and side != main:
             fork(side, main)
             with torch.cuda.stream(side):
                 _lib.call("hriemo_ln_pool_fwd", _p(xt), _p(h_t32), _p(kpm_t), _p(gt), _p(bt), _p(Tn), _p(mean_t), _p(rstd_t), _p(pt),
@@ -1990,7 +1995,23 @@ class BetaGateFn(_GradModeAware, torch.autograd.Function):
 
         main = torch.cuda.current_stream(dev)
         side = side_stream(dev) if GATE_TWO_STREAMS else None
-        if side is not None and side != main:
+        if GATE_PAIR and L_.hriemo_ln_pool_pair_supported(d):
+            nca_, nct_ = L_.hriemo_ln_pool_bwd_chunks(La), L_.hriemo_ln_pool_bwd_chunks(Lt)
+            if defer:
+                wsa, wst = torch.empty(nba // 4 + 16, **f32), torch.empty(nbt // 4 + 16, **f32)
+                outs = (None,) * 4
+            else:
+                wsa = workspace(nba + nbt + 256, dev, slot=1)
+                wst = wsa[(nba // 4 + 63) // 64 * 64:]
+                outs = (dga, dba, dgt, dbt)
+            _lib.call("hriemo_ln_pool_bwd_pair", _p(dH2), L, _p(w),
+                      _p(da), _p(kpm_a), _p(xa), _p(h_a32), _p(ga), _p(mean_a), _p(rstd_a), _p(dxa), _p(outs[0]), _p(outs[1]), La, _p(wsa),
+                      _p(dt), _p(kpm_t), _p(xt), _p(h_t32), _p(gt), _p(mean_t), _p(rstd_t), _p(dxt), _p(outs[2]), _p(outs[3]), Lt, _p(wst),
+                      int(acc), B, d, _stream())
+            if defer:
+                _deferred.add(wsa, 2 * d, B * nca_, d, 2, [dga, dba], True)
+                _deferred.add(wst, 2 * d, B * nct_, d, 2, [dgt, dbt], True)
+        elif side is not None and side != main:
             # text on the side stream (its own workspace there), audio on this one; joined before the gradients are handed back
             fork(side, main)
             with torch.cuda.stream(side):

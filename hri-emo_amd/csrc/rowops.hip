@@ -670,14 +670,14 @@ __global__ __launch_bounds__(ROWDOT_GROUPS * 32) void rowdot_bwd_kernel(const fl
 // ------------------------------------------------------------------ beta gate
 // LayerNorm every row of X[b, :, :]; write the first Lkeep rows; pooled partial sums over valid rows.
 template <int NCH, bool PF>
-__global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restrict__ X, const float* __restrict__ X32, const uint8_t* __restrict__ mask,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          bf16_t* __restrict__ Yn, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                          float* __restrict__ partials, int L, int Lkeep, int d, float eps) {
+__device__ __forceinline__ void ln_pool_fwd_body(const bf16_t* __restrict__ X, const float* __restrict__ X32, const uint8_t* __restrict__ mask,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 bf16_t* __restrict__ Yn, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                 float* __restrict__ partials, int L, int Lkeep, int d, float eps, int chunk, int nchunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = d >> 3;
+  const int b = blockIdx.y, nchunk = d >> 3;
   const float invd = 1.f / (float)d;
   float acc[NCH][8];
 #pragma unroll
@@ -739,8 +739,28 @@ __global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restri
     if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
   }
   block_colsum<NCH>(red, acc, nchunk, lane, wave, 4);
-  float* out = partials + ((long)b * gridDim.x + chunk) * d;
+  float* out = partials + ((long)b * nchunks + chunk) * d;
   for (int t = threadIdx.x; t < d; t += 256) out[t] = red[t];
+}
+template <int NCH, bool PF>
+__global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const bf16_t* __restrict__ X, const float* __restrict__ X32, const uint8_t* __restrict__ mask,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* __restrict__ Yn, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                          float* __restrict__ partials, int L, int Lkeep, int d, float eps) {
+  ln_pool_fwd_body<NCH, PF>(X, X32, mask, gamma, beta, Yn, mean_o, rstd_o, partials, L, Lkeep, d, eps, blockIdx.x, gridDim.x);
+}
+// Both modalities of the gate from ONE launch: blocks [0, nc of side 0) walk side 0, the rest side 1.  On two streams the pair
+// cost a fork and a join around each of the gate's two LayerNorm + pool steps (10-27 us of idle device each, profiles/
+// r04_step_timeline.txt); the blocks are the single kernel's, so are the results.
+struct PoolFwdSide { const bf16_t* X; const float* X32; const uint8_t* mask; const float* gamma; const float* beta; bf16_t* Yn; float* mean; float* rstd; float* partials; int L, Lkeep, nc; };
+struct PoolFwdPair { PoolFwdSide s[2]; };
+#define PAIR_PICK(f) (second ? p.s[1].f : p.s[0].f)      // field by field: an indexed copy of the argument struct would go to scratch
+template <int NCH, bool PF>
+__global__ __launch_bounds__(256) void ln_pool_fwd_pair_kernel(const PoolFwdPair p, int d, float eps) {
+  const bool second = (int)blockIdx.x >= p.s[0].nc;
+  ln_pool_fwd_body<NCH, PF>(PAIR_PICK(X), PAIR_PICK(X32), PAIR_PICK(mask), PAIR_PICK(gamma), PAIR_PICK(beta), PAIR_PICK(Yn), PAIR_PICK(mean),
+                            PAIR_PICK(rstd), PAIR_PICK(partials), PAIR_PICK(L), PAIR_PICK(Lkeep), d, eps,
+                            (int)blockIdx.x - (second ? p.s[0].nc : 0), PAIR_PICK(nc));
 }
 
 // pooled means + gate input [a, t, |a-t|, a*t]  (beta_gate_tacfn.py:83-89)
@@ -895,15 +915,15 @@ constexpr int POOL_BWD_ROWS = 16;
 // backward of LayerNorm+pool+fuse-branch for one modality:
 //   dYn[l] = (l < Lf ? coef * dH[b,l] : 0) + (valid_l ? dpool[b] : 0),  coef = is_a ? w : 1-w ;  dX = LN'(dYn)
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ w, int is_a,
-                                                          const float* __restrict__ dpool, const uint8_t* __restrict__ mask,
-                                                          const bf16_t* __restrict__ X, const float* __restrict__ X32, const float* __restrict__ gamma,
-                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                          bf16_t* __restrict__ dX, float* __restrict__ partials, int L, int d) {
+__device__ __forceinline__ void ln_pool_bwd_body(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ w, int is_a,
+                                                 const float* __restrict__ dpool, const uint8_t* __restrict__ mask,
+                                                 const bf16_t* __restrict__ X, const float* __restrict__ X32, const float* __restrict__ gamma,
+                                                 const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                 bf16_t* __restrict__ dX, float* __restrict__ partials, int L, int d, int chunk, int nchunks) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;   // [2][d] column-sum scratch (+ [3][d] constants for d <= 1024)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = d >> 3;
+  const int b = blockIdx.y, nchunk = d >> 3;
   const float invd = 1.f / (float)d;
   float ag[NCH][8], ab[NCH][8];
 #pragma unroll
@@ -1026,6 +1046,8 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
     if (PF && l + 4 < lend) load_row(l + 4);
     c1 = wave_sum(c1) * invd;
     c2 = wave_sum(c2) * invd;
+    asm volatile("" : "+v"(c1));      // two separate registers: as a pair they were fed to packed FMAs through the operand
+    asm volatile("" : "+v"(c2));      // select `make check-isa` rejects (wide rows, once this body was shared by two kernels)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
@@ -1039,8 +1061,25 @@ __global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restri
   }
   block_colsum<NCH>(red, ag, nchunk, lane, wave, 4);
   block_colsum<NCH>(red + d, ab, nchunk, lane, wave, 4);
-  float* out = partials + ((long)b * gridDim.x + chunk) * 2 * d;
+  float* out = partials + ((long)b * nchunks + chunk) * 2 * d;
   for (int t = threadIdx.x; t < 2 * d; t += 256) out[t] = red[t];
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_pool_bwd_kernel(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ w, int is_a,
+                                                          const float* __restrict__ dpool, const uint8_t* __restrict__ mask,
+                                                          const bf16_t* __restrict__ X, const float* __restrict__ X32, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          bf16_t* __restrict__ dX, float* __restrict__ partials, int L, int d) {
+  ln_pool_bwd_body<NCH>(dH, Lf, w, is_a, dpool, mask, X, X32, gamma, mean_i, rstd_i, dX, partials, L, d, blockIdx.x, gridDim.x);
+}
+// both modalities from one launch (see ln_pool_fwd_pair_kernel): side 0 = audio (coefficient w), side 1 = text (1 - w)
+struct PoolBwdSide { const float* dpool; const uint8_t* mask; const bf16_t* X; const float* X32; const float* gamma; const float* mean; const float* rstd; bf16_t* dX; float* partials; int L, nc; };
+struct PoolBwdPair { PoolBwdSide s[2]; };
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_pool_bwd_pair_kernel(const bf16_t* __restrict__ dH, int Lf, const float* __restrict__ w, const PoolBwdPair p, int d) {
+  const bool second = (int)blockIdx.x >= p.s[0].nc;
+  ln_pool_bwd_body<NCH>(dH, Lf, w, second ? 0 : 1, PAIR_PICK(dpool), PAIR_PICK(mask), PAIR_PICK(X), PAIR_PICK(X32), PAIR_PICK(gamma), PAIR_PICK(mean),
+                        PAIR_PICK(rstd), PAIR_PICK(dX), PAIR_PICK(partials), PAIR_PICK(L), d, (int)blockIdx.x - (second ? p.s[0].nc : 0), PAIR_PICK(nc));
 }
 
 // ================================================================== host entry points
@@ -1604,6 +1643,28 @@ extern "C" int hriemo_ln_pool_fwd(const void* X, const float* X32, const unsigne
   return 0;
 }
 
+// the gate's two LayerNorm + pool steps from one launch (side 0 = audio, side 1 = text; same d, B, eps): see ln_pool_fwd_pair_kernel
+extern "C" int hriemo_ln_pool_pair_supported(int d) { return d % 8 == 0 && d <= 1024 ? 1 : 0; }
+extern "C" int hriemo_ln_pool_fwd_pair(const void* Xa, const float* Xa32, const unsigned char* mask_a, const float* gamma_a, const float* beta_a,
+                                       void* Yna, float* mean_a, float* rstd_a, float* partials_a, int La,
+                                       const void* Xt, const float* Xt32, const unsigned char* mask_t, const float* gamma_t, const float* beta_t,
+                                       void* Ynt, float* mean_t, float* rstd_t, float* partials_t, int Lt,
+                                       int B, int Lkeep, int d, float eps, hipStream_t st) {
+  if (check_rows(B * La, d) || check_rows(B * Lt, d)) return 1;
+  HRIEMO_CHECK(Lkeep >= 0 && Lkeep <= La && Lkeep <= Lt, "ln_pool_fwd_pair: Lkeep=%d out of range (La=%d, Lt=%d)", Lkeep, La, Lt);
+  HRIEMO_CHECK(hriemo_ln_pool_pair_supported(d), "ln_pool_fwd_pair: d=%d (pairs are built for d <= 1024; use two hriemo_ln_pool_fwd calls)", d);
+  PoolFwdPair p;
+  p.s[0] = PoolFwdSide{(const bf16_t*)Xa, Xa32, mask_a, gamma_a, beta_a, (bf16_t*)Yna, mean_a, rstd_a, partials_a, La, Lkeep, (La + 31) / 32};
+  p.s[1] = PoolFwdSide{(const bf16_t*)Xt, Xt32, mask_t, gamma_t, beta_t, (bf16_t*)Ynt, mean_t, rstd_t, partials_t, Lt, Lkeep, (Lt + 31) / 32};
+  const int nc = p.s[0].nc + p.s[1].nc;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  if (d <= 512) hipLaunchKernelGGL((ln_pool_fwd_pair_kernel<1, true>), dim3(nc, B), dim3(256), d * 4, st, p, d, eps);
+  else hipLaunchKernelGGL((ln_pool_fwd_pair_kernel<2, true>), dim3(nc, B), dim3(256), d * 4, st, p, d, eps);
+  HRIEMO_LAUNCH_CHECK("ln_pool_fwd_pair_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, ((double)B * (La + Lt) + 2.0 * B * Lkeep) * d * 2);
+  return 0;
+}
+
 extern "C" int hriemo_gate_input(const float* partials_a, const float* partials_t, const unsigned char* mask_a,
                                  const unsigned char* mask_t, int B, int La, int Lt, int d, void* gate_in, float* a_pool,
                                  float* t_pool, float* cnt, hipStream_t st) {
@@ -1739,5 +1800,38 @@ extern "C" int hriemo_ln_pool_bwd(const void* dH, int Lf, const float* w, int is
   ReduceOut ro; ro.o[0] = dgamma; ro.o[1] = dbeta; ro.o[2] = nullptr;
   launch_colreduce(workspace, (long)2 * d, B * nc, ro, d, 2, accumulate, scratch, st);
   HRIEMO_LAUNCH_CHECK("colreduce_kernel");
+  return 0;
+}
+
+// both modalities' gate backward from one launch (side 0 = audio: coefficient w, side 1 = text: 1 - w).  dgamma / dbeta as in the
+// single call: finished here when given, else the partial sums stay in each side's workspace for the launch-boundary reduce
+extern "C" int hriemo_ln_pool_bwd_pair(const void* dH, int Lf, const float* w,
+                                       const float* dpool_a, const unsigned char* mask_a, const void* Xa, const float* Xa32, const float* gamma_a,
+                                       const float* mean_a, const float* rstd_a, void* dXa, float* dgamma_a, float* dbeta_a, int La, float* workspace_a,
+                                       const float* dpool_t, const unsigned char* mask_t, const void* Xt, const float* Xt32, const float* gamma_t,
+                                       const float* mean_t, const float* rstd_t, void* dXt, float* dgamma_t, float* dbeta_t, int Lt, float* workspace_t,
+                                       int accumulate, int B, int d, hipStream_t st) {
+  if (check_rows(B * La, d) || check_rows(B * Lt, d)) return 1;
+  HRIEMO_CHECK(workspace_a != nullptr && workspace_t != nullptr && workspace_a != workspace_t && Lf <= La && Lf <= Lt, "ln_pool_bwd_pair: bad arguments");
+  HRIEMO_CHECK(hriemo_ln_pool_pair_supported(d), "ln_pool_bwd_pair: d=%d (pairs are built for d <= 1024; use two hriemo_ln_pool_bwd calls)", d);
+  HRIEMO_CHECK((dgamma_a == nullptr) == (dbeta_a == nullptr) && (dgamma_t == nullptr) == (dbeta_t == nullptr) && (dgamma_a == nullptr) == (dgamma_t == nullptr),
+               "ln_pool_bwd_pair: the four LayerNorm gradients come together or not at all");
+  PoolBwdPair p;
+  p.s[0] = PoolBwdSide{dpool_a, mask_a, (const bf16_t*)Xa, Xa32, gamma_a, mean_a, rstd_a, (bf16_t*)dXa, workspace_a, La, hriemo_ln_pool_bwd_chunks(La)};
+  p.s[1] = PoolBwdSide{dpool_t, mask_t, (const bf16_t*)Xt, Xt32, gamma_t, mean_t, rstd_t, (bf16_t*)dXt, workspace_t, Lt, hriemo_ln_pool_bwd_chunks(Lt)};
+  const int nc = p.s[0].nc + p.s[1].nc;
+  hriemo_prof_begin(HP_ROWOPS, st);
+  if (d <= 512) hipLaunchKernelGGL((ln_pool_bwd_pair_kernel<1>), dim3(nc, B), dim3(256), 5 * d * 4, st, (const bf16_t*)dH, Lf, w, p, d);
+  else hipLaunchKernelGGL((ln_pool_bwd_pair_kernel<2>), dim3(nc, B), dim3(256), 5 * d * 4, st, (const bf16_t*)dH, Lf, w, p, d);
+  HRIEMO_LAUNCH_CHECK("ln_pool_bwd_pair_kernel");
+  hriemo_prof_end(HP_ROWOPS, st, (2.0 * B * (La + Lt) + 2.0 * B * Lf) * d * 2);
+  if (dgamma_a == nullptr) return 0;
+  for (int side = 0; side < 2; ++side) {
+    float* ws = side ? workspace_t : workspace_a;
+    float* scratch = ws + (long)B * p.s[side].nc * 2 * d;
+    ReduceOut ro; ro.o[0] = side ? dgamma_t : dgamma_a; ro.o[1] = side ? dbeta_t : dbeta_a; ro.o[2] = nullptr;
+    launch_colreduce(ws, (long)2 * d, B * p.s[side].nc, ro, d, 2, accumulate, scratch, st);
+    HRIEMO_LAUNCH_CHECK("colreduce_kernel");
+  }
   return 0;
 }

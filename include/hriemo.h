@@ -303,6 +303,21 @@ int hriemo_colsum_partial_rows(int M, int N);
 int hriemo_colreduce_batch(const void* jobs_host, int njobs, void* jobs_dev, int nblocks, hriemo_stream_t stream);
 /* tuning hook: `blocks` CUs made unavailable for ~`micros` us (stands in for a collective running beside the step) */
 int hriemo_debug_hog(int blocks, int micros, float* sink, hriemo_stream_t stream);
+/* The gate's two modalities from ONE launch (d <= 1024: hriemo_ln_pool_pair_supported): side a = audio (gate coefficient w), side t =
+ * text (1 - w); the blocks are those of the single calls, so are the results.  Replaces two launches on two streams and the fork /
+ * join around them (models/beta_gate_tacfn.py:79-84 forward, its autograd backward). */
+int hriemo_ln_pool_pair_supported(int d);
+int hriemo_ln_pool_fwd_pair(const void* Xa, const float* Xa32, const unsigned char* mask_a, const float* gamma_a, const float* beta_a,
+                            void* Yna, float* mean_a, float* rstd_a, float* partials_a, int La,
+                            const void* Xt, const float* Xt32, const unsigned char* mask_t, const float* gamma_t, const float* beta_t,
+                            void* Ynt, float* mean_t, float* rstd_t, float* partials_t, int Lt,
+                            int B, int Lkeep, int d, float eps, hriemo_stream_t stream);
+int hriemo_ln_pool_bwd_pair(const void* dH, int Lf, const float* w,
+                            const float* dpool_a, const unsigned char* mask_a, const void* Xa, const float* Xa32, const float* gamma_a,
+                            const float* mean_a, const float* rstd_a, void* dXa, float* dgamma_a, float* dbeta_a, int La, float* workspace_a,
+                            const float* dpool_t, const unsigned char* mask_t, const void* Xt, const float* Xt32, const float* gamma_t,
+                            const float* mean_t, const float* rstd_t, void* dXt, float* dgamma_t, float* dbeta_t, int Lt, float* workspace_t,
+                            int accumulate, int B, int d, hriemo_stream_t stream);
 /* row chunks per sample of hriemo_ln_pool_bwd: its partial sums are [B * chunks][2 d] floats at the head of `workspace` */
 int hriemo_ln_pool_bwd_chunks(int L);
 long hriemo_ln_pool_bwd_workspace_bytes(int B, int L, int d);

@@ -409,3 +409,78 @@ def test_expand_rows_with_fp32_twin_and_seed_bump(lib):
         want = (want + 0x9E3779B97F4A7C15) & ((1 << 64) - 1)
     got = int(word.item()) & ((1 << 64) - 1)
     assert got == want, (hex(got), hex(want))
+
+
+@pytest.mark.parametrize("B,La,Lt,d,masked,twin", [c for c in GATE_CASES if c[3] <= 1024] + [(64, 400, 128, 768, True, True)])
+def test_ln_pool_pair_launch_equals_the_two_single_launches(lib, B, La, Lt, d, masked, twin):
+    """hriemo_ln_pool_fwd_pair / hriemo_ln_pool_bwd_pair: both modalities of the gate (models/beta_gate_tacfn.py:79-84 and its
+    backward) from ONE launch instead of two on two streams.  The blocks run the single launches' code on the same operands, so
+    every output -- normalised rows, mean / rstd, pooled partial sums; dX, and dgamma / dbeta through the same column reduce --
+    must hold the same bits (bit-exact, like the rest of the integer-free but order-fixed row kernels)."""
+    assert lib.lib().hriemo_ln_pool_pair_supported(d) == 1 and lib.lib().hriemo_ln_pool_pair_supported(2048) == 0
+    g = torch.Generator().manual_seed(B * 131 + La)
+    L = La if La == Lt else Lt
+    if La < L:
+        pytest.skip("audio shorter than text: the reference cannot fuse this either")
+
+    def side(Lx, seed):
+        gg = torch.Generator().manual_seed(seed)
+        x32 = torch.randn(B, Lx, d, generator=gg).cuda()
+        x = x32.bfloat16()
+        m = ragged_mask(B, Lx, gg).cuda().to(torch.uint8) if masked else None
+        return x, (x32 if twin else None), m, (1 + 0.1 * torch.randn(d, generator=gg)).cuda(), (0.1 * torch.randn(d, generator=gg)).cuda()
+
+    xa, xa32, ma, ga, ba = side(La, 1)
+    xt, xt32, mt, gt, bt = side(Lt, 2)
+    nca, nct = lib.lib().hriemo_pool_chunks(La), lib.lib().hriemo_pool_chunks(Lt)
+
+    def fwd_outs():
+        return dict(An=bf(B, L, d).zero_(), Tn=bf(B, L, d).zero_(), mean_a=f32(B * La), rstd_a=f32(B * La), mean_t=f32(B * Lt), rstd_t=f32(B * Lt),
+                    pa=f32(B, nca, d), pt=f32(B, nct, d))
+
+    s, p = fwd_outs(), fwd_outs()
+    lib.call("hriemo_ln_pool_fwd", P(xa), P(xa32), P(ma), P(ga), P(ba), P(s["An"]), P(s["mean_a"]), P(s["rstd_a"]), P(s["pa"]), B, La, L, d, 1e-5, ST())
+    lib.call("hriemo_ln_pool_fwd", P(xt), P(xt32), P(mt), P(gt), P(bt), P(s["Tn"]), P(s["mean_t"]), P(s["rstd_t"]), P(s["pt"]), B, Lt, L, d, 1e-5, ST())
+    lib.call("hriemo_ln_pool_fwd_pair", P(xa), P(xa32), P(ma), P(ga), P(ba), P(p["An"]), P(p["mean_a"]), P(p["rstd_a"]), P(p["pa"]), La,
+             P(xt), P(xt32), P(mt), P(gt), P(bt), P(p["Tn"]), P(p["mean_t"]), P(p["rstd_t"]), P(p["pt"]), Lt, B, L, d, 1e-5, ST())
+    torch.cuda.synchronize()
+    for k in s:
+        assert torch.equal(s[k], p[k]), ("forward", k)
+        assert torch.isfinite(s[k].float()).all(), k
+
+    dH = (0.1 * torch.randn(B, L, d, generator=g)).cuda().bfloat16()
+    w = torch.rand(B, d, generator=g).cuda()
+    da, dt = (0.01 * torch.randn(B, d, generator=g)).cuda(), (0.01 * torch.randn(B, d, generator=g)).cuda()
+    nba, nbt = lib.lib().hriemo_ln_pool_bwd_workspace_bytes(B, La, d), lib.lib().hriemo_ln_pool_bwd_workspace_bytes(B, Lt, d)
+
+    def bwd_outs():
+        return dict(dxa=bf(B, La, d), dxt=bf(B, Lt, d), dga=f32(d).fill_(0.5), dba=f32(d).fill_(0.25), dgt=f32(d).fill_(-0.5), dbt=f32(d).fill_(1.0))
+
+    for acc in (0, 1):
+        s, p = bwd_outs(), bwd_outs()
+        wsa, wst = f32(nba // 4 + 16), f32(nbt // 4 + 16)
+        fo = fwd_outs()                     # statistics of the forward (recomputed by the single launches, shared by both paths)
+        lib.call("hriemo_ln_pool_fwd", P(xa), P(xa32), P(ma), P(ga), P(ba), P(fo["An"]), P(fo["mean_a"]), P(fo["rstd_a"]), P(fo["pa"]), B, La, L, d, 1e-5, ST())
+        lib.call("hriemo_ln_pool_fwd", P(xt), P(xt32), P(mt), P(gt), P(bt), P(fo["Tn"]), P(fo["mean_t"]), P(fo["rstd_t"]), P(fo["pt"]), B, Lt, L, d, 1e-5, ST())
+        lib.call("hriemo_ln_pool_bwd", P(dH), L, P(w), 1, P(da), P(ma), P(xa), P(xa32), P(ga), P(fo["mean_a"]), P(fo["rstd_a"]), P(s["dxa"]),
+                 P(s["dga"]), P(s["dba"]), acc, B, La, d, P(wsa), ST())
+        lib.call("hriemo_ln_pool_bwd", P(dH), L, P(w), 0, P(dt), P(mt), P(xt), P(xt32), P(gt), P(fo["mean_t"]), P(fo["rstd_t"]), P(s["dxt"]),
+                 P(s["dgt"]), P(s["dbt"]), acc, B, Lt, d, P(wst), ST())
+        wsa2, wst2 = f32(nba // 4 + 16), f32(nbt // 4 + 16)
+        lib.call("hriemo_ln_pool_bwd_pair", P(dH), L, P(w),
+                 P(da), P(ma), P(xa), P(xa32), P(ga), P(fo["mean_a"]), P(fo["rstd_a"]), P(p["dxa"]), P(p["dga"]), P(p["dba"]), La, P(wsa2),
+                 P(dt), P(mt), P(xt), P(xt32), P(gt), P(fo["mean_t"]), P(fo["rstd_t"]), P(p["dxt"]), P(p["dgt"]), P(p["dbt"]), Lt, P(wst2),
+                 acc, B, d, ST())
+        torch.cuda.synchronize()
+        for k in s:
+            assert torch.equal(s[k], p[k]), ("backward", acc, k)
+            assert torch.isfinite(s[k].float()).all(), k
+    # partial sums left in the workspaces when no dgamma / dbeta is given (the launch-boundary reduce finishes them): same words
+    nch_a, nch_t = lib.lib().hriemo_ln_pool_bwd_chunks(La), lib.lib().hriemo_ln_pool_bwd_chunks(Lt)
+    wsa3, wst3 = f32(nba // 4 + 16).zero_(), f32(nbt // 4 + 16).zero_()
+    q = bwd_outs()
+    lib.call("hriemo_ln_pool_bwd_pair", P(dH), L, P(w),
+             P(da), P(ma), P(xa), P(xa32), P(ga), P(fo["mean_a"]), P(fo["rstd_a"]), P(q["dxa"]), None, None, La, P(wsa3),
+             P(dt), P(mt), P(xt), P(xt32), P(gt), P(fo["mean_t"]), P(fo["rstd_t"]), P(q["dxt"]), None, None, Lt, P(wst3), 1, B, d, ST())
+    torch.cuda.synchronize()
+    assert torch.equal(wsa3[:B * nch_a * 2 * d], wsa2[:B * nch_a * 2 * d]) and torch.equal(wst3[:B * nch_t * 2 * d], wst2[:B * nch_t * 2 * d])
