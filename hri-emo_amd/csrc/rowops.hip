@@ -756,7 +756,7 @@ struct PoolFwdSide { const bf16_t* X; const float* X32; const uint8_t* mask; con
 struct PoolFwdPair { PoolFwdSide s[2]; };
 #define PAIR_PICK(f) (second ? p.s[1].f : p.s[0].f)      // field by field: an indexed copy of the argument struct would go to scratch
 template <int NCH, bool PF>
-__global__ __launch_bounds__(256) void ln_pool_fwd_pair_kernel(const PoolFwdPair p, int d, float eps) {
+__global__ __launch_bounds__(256, 4) void ln_pool_fwd_pair_kernel(const PoolFwdPair p, int d, float eps) {
   const bool second = (int)blockIdx.x >= p.s[0].nc;
   ln_pool_fwd_body<NCH, PF>(PAIR_PICK(X), PAIR_PICK(X32), PAIR_PICK(mask), PAIR_PICK(gamma), PAIR_PICK(beta), PAIR_PICK(Yn), PAIR_PICK(mean),
                             PAIR_PICK(rstd), PAIR_PICK(partials), PAIR_PICK(L), PAIR_PICK(Lkeep), d, eps,
